@@ -1,0 +1,122 @@
+/* littlegan_hip — C ABI of the MI355X (gfx950) kernels for the LittleGAN training-step hot path.
+ *
+ * Drop-in boundary: the reference has no FFI; its hot path sits behind Python objects
+ * (model.py Generator/Discriminator/Adjuster, eager_trainer.py EagerTrainer) whose arithmetic TensorFlow
+ * executes.  Each entry point below replaces the TF op(s) named in its comment (file:line relative to
+ * /root/reference).  Conventions:
+ *   - every pointer is a DEVICE pointer (fp32 unless stated), tensors are NHWC, row-major, dense;
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work, never allocate or synchronise
+ *     (graph-capturable); scratch comes from caller-provided workspaces sized by *_workspace_bytes();
+ *   - return 0 on success, <0 on error (LG_ERR_*), message via lg_last_error(); no exceptions, no global
+ *     state besides the thread-local error string;
+ *   - `dtype` selects the MFMA operand type of the contraction: LG_DT_F32 = exact f32
+ *     (v_mfma_f32_32x32x2_f32), LG_DT_BF16 = bf16 operands / f32 accumulate (v_mfma_f32_32x32x16_bf16).
+ *     Storage in HBM is fp32 either way.
+ * Stride-2 layers are described by (cb, cs, Hs, Ws): cb = channels of the BIG (2Hs x 2Ws) tensor,
+ * cs = channels of the SMALL (Hs x Ws) tensor.  tf Conv2D kernels (HWIO, in=cb, out=cs) and
+ * Conv2DTranspose kernels (HWOI, out=cb, in=cs) then share ONE memory layout [5][5][cb][cs].
+ */
+#ifndef LITTLEGAN_HIP_H
+#define LITTLEGAN_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LG_ABI_VERSION 1
+#define LG_OK 0
+#define LG_ERR_ARG (-1)
+#define LG_ERR_LAUNCH (-2)
+#define LG_ERR_UNSUPPORTED (-3)
+#define LG_DT_F32 0
+#define LG_DT_BF16 1
+
+int lg_abi_version(void);
+const char* lg_last_error(void);
+
+/* ---- weight packing (once per layer per step; weights change every step) ------------------------
+ * master kernel w[5][5][cb][cs] -> MFMA B-operand images in `dtype` (down pack + up pack). */
+size_t lg_conv_pack_bytes(int cb, int cs, int dtype);
+int lg_conv_pack(const float* w, void* pack, int cb, int cs, int dtype, void* stream);
+
+/* ---- tf.compat.v1.layers.Conv2D(f,5,2,"same")  model.py:15 (Encoder) ----------------------------- */
+/* y[B,Hs,Ws,cs] = conv(x[B,2Hs,2Ws,cb]) + bias ; cb == 3 uses the 3-channel patch kernel */
+int lg_conv2d_s2_fwd(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws, int cb,
+                     int cs, int dtype, void* stream);
+/* dx[B,2Hs,2Ws,cb] = conv2d_backprop_input(dy[B,Hs,Ws,cs]) */
+int lg_conv2d_s2_dgrad(const float* dy, const void* pack, float* dx, int B, int Hs, int Ws, int cb, int cs, int dtype,
+                       void* stream);
+/* dw[5][5][cb][cs] (+)= conv2d_backprop_filter(x, dy) */
+int lg_conv2d_s2_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t ws_bytes, int B, int Hs,
+                       int Ws, int cb, int cs, int accumulate, int dtype, void* stream);
+
+/* ---- tf.compat.v1.layers.Conv2DTranspose(f,5,(2,2),"same")  model.py:39-40 (Decoder) ------------- */
+/* y[B,2Hs,2Ws,cb] = convT(x[B,Hs,Ws,cs]) + bias   (4-phase sub-pixel implicit GEMM) */
+int lg_convT_s2_fwd(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws, int cb,
+                    int cs, int dtype, void* stream);
+int lg_convT_s2_dgrad(const float* dy, const void* pack, float* dx, int B, int Hs, int Ws, int cb, int cs, int dtype,
+                      void* stream);
+int lg_convT_s2_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t ws_bytes, int B, int Hs,
+                      int Ws, int cb, int cs, int accumulate, int dtype, void* stream);
+size_t lg_wgrad_workspace_bytes(int B, int Hs, int Ws, int cb, int cs, int dtype);
+
+/* ---- Conv2DTranspose(image_channel,5,(1,1),"same",activation="tanh")  model.py:86-87 ------------- */
+/* y[B,H,W,cb] = tanh(convT_s1(x[B,H,W,cs]) + bias) ; kernel [5][5][cb][cs], cb = image channels (3) */
+int lg_convT_s1_tanh_fwd(const float* x, const void* pack, const float* bias, float* y, int B, int H, int W, int cb,
+                         int cs, int dtype, void* stream);
+/* given dpre = dL/d(pre-tanh) [B,H,W,cb]: dx[B,H,W,cs] (may be null), dw (+)=, db (+)= (dw/db may be null) */
+int lg_convT_s1_tanh_bwd(const float* x, const float* dpre, const void* pack, float* dx, float* dw, float* db,
+                         void* workspace, size_t ws_bytes, int B, int H, int W, int cb, int cs, int accumulate,
+                         int dtype, void* stream);
+size_t lg_convT_s1_bwd_workspace_bytes(int B, int H, int W, int cb, int cs, int dtype);
+
+/* bias gradient of any conv layer: db[C] (+)= column sums of dy[M][C]  (C % 4 == 0) */
+size_t lg_bias_grad_workspace_bytes(long long M, int C);
+int lg_bias_grad(const float* dy, float* db, void* workspace, size_t ws_bytes, long long M, int C, int accumulate,
+                 void* stream);
+
+/* ---- InstanceNormalization(axis=None) + LeakyReLU + skip add  instance.py:105-128, model.py:24,46-50 */
+size_t lg_instnorm_workspace_bytes(int B, long long L);
+/* stats[B][4] = {mu, sigma, a, b} of (pre_leaky ? leaky(x) : x); a = gamma/(sigma+1e-3), b = beta - a*mu */
+int lg_instnorm_leaky_stats(const float* x, float* stats, const float* gamma, const float* beta, void* workspace,
+                            size_t ws_bytes, int B, long long L, int pre_leaky, float alpha, void* stream);
+/* y = [post_leaky](a*[pre_leaky](x) + b) [+ skip] */
+int lg_instnorm_leaky_apply(const float* x, const float* stats, const float* skip, float* y, int B, long long L,
+                            int pre_leaky, int post_leaky, float alpha, void* stream);
+/* g = dL/dy (before skip) -> dx ; dgamma/dbeta (device scalars, may be null) */
+int lg_instnorm_leaky_bwd(const float* x, const float* stats, const float* g, float* dx, float* dgamma, float* dbeta,
+                          void* workspace, size_t ws_bytes, int B, long long L, int pre_leaky, int post_leaky,
+                          float alpha, int accumulate, void* stream);
+
+/* ---- tf.compat.v1.layers.Dense  model.py:62-63 (heads, sigmoid), :83, :120 ----------------------- */
+int lg_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, void* stream);
+int lg_dense_wgrad(const float* x, const float* dy, float* dw, float* db, int B, int K, int N, int accumulate,
+                   void* stream);
+/* p[B][1+c] = sigmoid(x[B][K] @ [wpr | wc] + [bpr | bc]) : column 0 = output_pr, 1.. = output_cond */
+int lg_heads_fwd(const float* x, const float* wpr, const float* bpr, const float* wc, const float* bc, float* p, int B,
+                 int K, int c, void* stream);
+int lg_heads_dgrad(const float* dz, const float* wpr, const float* wc, float* dx, int B, int K, int c, void* stream);
+int lg_heads_wgrad(const float* x, const float* dz, float* dwpr, float* dbpr, float* dwc, float* dbc, int B, int K,
+                   int c, int accumulate, void* stream);
+
+/* ---- losses  eager_trainer.py:85-102 -------------------------------------------------------------- */
+/* loss (+)= w_pr*mean BCE(t_pr, p[:,0]) + w_c*mean BCE(t_c, p[:,1:]) ; dz[B][1+c] = dloss/dlogits */
+int lg_bce_heads_loss_fwd_bwd(const float* p, const float* t_c, float t_pr, float w_pr, float w_c, float* loss,
+                              float* dz, int B, int c, int accumulate, void* stream);
+size_t lg_l1_workspace_bytes(void);
+/* loss (+)= lambda*mean|t-img| ; dpre = (g_in - lambda*sign(t-img)/n)*(1-img^2) (g_in, dpre may be null) */
+int lg_l1_tanh_loss_fwd_bwd(const float* t, const float* img, const float* g_in, float* dpre, float* loss,
+                            void* workspace, size_t ws_bytes, long long n, float lambda, int accumulate, void* stream);
+
+/* ---- tf.clip_by_value + tf.compat.v1.train.AdamOptimizer  eager_trainer.py:28-30,146-148,164-168 -- */
+/* state = {beta1_power, beta2_power} on the device; g is scaled by gscale (1/world_size) then clipped */
+int lg_clip_adam_update(float* w, const float* g, float* m, float* v, long long n, const float* state, float lr,
+                        float b1, float b2, float eps, float clip, float gscale, void* stream);
+int lg_adam_advance(float* state, float b1, float b2, void* stream);
+int lg_axpby(float* y, const float* x, float a, float b, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,84 @@
+"""ctypes binding of liblittlegan_hip.so (C ABI: include/littlegan_hip.h).
+
+The product path has NO fallback: if the shared library is missing this module raises at
+import of the symbol table, and every op raises `LittleGanHipError` on a non-zero return.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblittlegan_hip.so")
+
+DT_F32, DT_BF16 = 0, 1
+
+P, I, L, F, Z = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+
+# name -> (restype, [argtypes])
+SIGNATURES = {
+    "lg_abi_version": (I, []),
+    "lg_last_error": (C.c_char_p, []),
+    "lg_conv_pack_bytes": (Z, [I, I, I]),
+    "lg_conv_pack": (I, [P, P, I, I, I, P]),
+    "lg_conv2d_s2_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "lg_conv2d_s2_dgrad": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "lg_conv2d_s2_wgrad": (I, [P, P, P, P, Z, I, I, I, I, I, I, I, P]),
+    "lg_convT_s2_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "lg_convT_s2_dgrad": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "lg_convT_s2_wgrad": (I, [P, P, P, P, Z, I, I, I, I, I, I, I, P]),
+    "lg_wgrad_workspace_bytes": (Z, [I, I, I, I, I, I]),
+    "lg_convT_s1_tanh_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "lg_convT_s1_tanh_bwd": (I, [P, P, P, P, P, P, P, Z, I, I, I, I, I, I, I, P]),
+    "lg_convT_s1_bwd_workspace_bytes": (Z, [I, I, I, I, I, I]),
+    "lg_bias_grad_workspace_bytes": (Z, [L, I]),
+    "lg_bias_grad": (I, [P, P, P, Z, L, I, I, P]),
+    "lg_instnorm_workspace_bytes": (Z, [I, L]),
+    "lg_instnorm_leaky_stats": (I, [P, P, P, P, P, Z, I, L, I, F, P]),
+    "lg_instnorm_leaky_apply": (I, [P, P, P, P, I, L, I, I, F, P]),
+    "lg_instnorm_leaky_bwd": (I, [P, P, P, P, P, P, P, Z, I, L, I, I, F, I, P]),
+    "lg_dense_fwd": (I, [P, P, P, P, I, I, I, P]),
+    "lg_dense_wgrad": (I, [P, P, P, P, I, I, I, I, P]),
+    "lg_heads_fwd": (I, [P, P, P, P, P, P, I, I, I, P]),
+    "lg_heads_dgrad": (I, [P, P, P, P, I, I, I, P]),
+    "lg_heads_wgrad": (I, [P, P, P, P, P, P, I, I, I, I, P]),
+    "lg_bce_heads_loss_fwd_bwd": (I, [P, P, F, F, F, P, P, I, I, I, P]),
+    "lg_l1_workspace_bytes": (Z, []),
+    "lg_l1_tanh_loss_fwd_bwd": (I, [P, P, P, P, P, P, Z, L, F, I, P]),
+    "lg_clip_adam_update": (I, [P, P, P, P, L, P, F, F, F, F, F, F, P]),
+    "lg_adam_advance": (I, [P, F, F, P]),
+    "lg_axpby": (I, [P, P, F, F, L, P]),
+}
+
+
+class LittleGanHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads the HIP library (once).  Raises if it has not been built: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LittleGanHipError(
+            f"{LIB_PATH} not found: build it with `python -m littlegan_amd.csrc.build` "
+            "(the LittleGAN hot path has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.lg_abi_version() != 1:
+        raise LittleGanHipError("liblittlegan_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().lg_last_error().decode("utf-8", "replace")
+        raise LittleGanHipError(f"{what} failed (rc={rc}): {msg}")

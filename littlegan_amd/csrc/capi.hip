@@ -1,0 +1,142 @@
+// Typed C-ABI entry points (include/littlegan_hip.h) on top of the shared kernels.
+#include <stdarg.h>
+#include <stdio.h>
+#include "lg_common.h"
+#include "../../include/littlegan_hip.h"
+
+static thread_local char g_err[512] = "";
+
+extern "C" void lg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* lg_last_error(void) { return g_err; }
+extern "C" int lg_abi_version(void) { return LG_ABI_VERSION; }
+
+extern "C" int lg_conv_igemm(int mode, int dtype, const float* src, const void* wpack, const float* bias, float* out,
+                             int B, int Hm, int Wm, int Cs, int N, int act, int pstride, int ppad, void* stream);
+extern "C" size_t lg_conv_pack_up_offset(int cb, int cs, int dtype);
+extern "C" int lg_conv_wgrad(const float* big, const float* small, float* dw, void* workspace, size_t ws_bytes, int B,
+                             int Hm, int Wm, int cb, int cs, int pstride, int ppad, int accumulate, int dtype,
+                             void* stream);
+
+enum { MODE_DOWN = 0, MODE_UP = 1, MODE_S1T = 2, MODE_PATCH = 3 };
+
+static inline const void* up_pack(const void* pack, int cb, int cs, int dtype) {
+  return (const char*)pack + lg_conv_pack_up_offset(cb, cs, dtype);
+}
+
+// "down": big [B,2Hs,2Ws,cb] -> small [B,Hs,Ws,cs]
+static int run_down(const float* big, const void* pack, const float* bias, float* small, int B, int Hs, int Ws, int cb,
+                    int cs, int dtype, void* stream) {
+  if (cb == 3) return lg_conv_igemm(MODE_PATCH, dtype, big, pack, bias, small, B, Hs, Ws, 3, cs, 0, 2, 1, stream);
+  return lg_conv_igemm(MODE_DOWN, dtype, big, pack, bias, small, B, Hs, Ws, cb, cs, 0, 0, 0, stream);
+}
+// "up": small [B,Hs,Ws,cs] -> big [B,2Hs,2Ws,cb]
+static int run_up(const float* small, const void* pack, const float* bias, float* big, int B, int Hs, int Ws, int cb,
+                  int cs, int dtype, void* stream) {
+  return lg_conv_igemm(MODE_UP, dtype, small, up_pack(pack, cb, cs, dtype), bias, big, B, Hs, Ws, cs, cb, 0, 0, 0,
+                       stream);
+}
+
+extern "C" int lg_conv2d_s2_fwd(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws,
+                                int cb, int cs, int dtype, void* stream) {
+  return run_down(x, pack, bias, y, B, Hs, Ws, cb, cs, dtype, stream);
+}
+extern "C" int lg_conv2d_s2_dgrad(const float* dy, const void* pack, float* dx, int B, int Hs, int Ws, int cb, int cs,
+                                  int dtype, void* stream) {
+  return run_up(dy, pack, nullptr, dx, B, Hs, Ws, cb, cs, dtype, stream);
+}
+extern "C" int lg_conv2d_s2_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t ws_bytes, int B,
+                                  int Hs, int Ws, int cb, int cs, int accumulate, int dtype, void* stream) {
+  return lg_conv_wgrad(x, dy, dw, workspace, ws_bytes, B, Hs, Ws, cb, cs, 2, 1, accumulate, dtype, stream);
+}
+extern "C" int lg_convT_s2_fwd(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws,
+                               int cb, int cs, int dtype, void* stream) {
+  return run_up(x, pack, bias, y, B, Hs, Ws, cb, cs, dtype, stream);
+}
+extern "C" int lg_convT_s2_dgrad(const float* dy, const void* pack, float* dx, int B, int Hs, int Ws, int cb, int cs,
+                                 int dtype, void* stream) {
+  return run_down(dy, pack, nullptr, dx, B, Hs, Ws, cb, cs, dtype, stream);
+}
+extern "C" int lg_convT_s2_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t ws_bytes, int B,
+                                 int Hs, int Ws, int cb, int cs, int accumulate, int dtype, void* stream) {
+  return lg_conv_wgrad(dy, x, dw, workspace, ws_bytes, B, Hs, Ws, cb, cs, 2, 1, accumulate, dtype, stream);
+}
+
+extern "C" int lg_convT_s1_tanh_fwd(const float* x, const void* pack, const float* bias, float* y, int B, int H, int W,
+                                    int cb, int cs, int dtype, void* stream) {
+  return lg_conv_igemm(MODE_S1T, dtype, x, up_pack(pack, cb, cs, dtype), bias, y, B, H, W, cs, cb, 1, 0, 0, stream);
+}
+
+namespace {
+// column sums of [M][3] (M % 4 == 0): 12 floats = 4 pixels per thread-iteration
+__global__ __launch_bounds__(256) void colsum3_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                      long long n12) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  float s[3] = {0.f, 0.f, 0.f};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n12; i += stride) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 12);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(x + i * 12 + 4);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(x + i * 12 + 8);
+    s[0] += (a[0] + a[3]) + (b[2] + c[1]);
+    s[1] += (a[1] + b[0]) + (b[3] + c[2]);
+    s[2] += (a[2] + b[1]) + (c[0] + c[3]);
+  }
+  __shared__ float sred[48];
+  lg_block_sum<3>(s, sred);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x * 3 + 0] = s[0];
+    partial[blockIdx.x * 3 + 1] = s[1];
+    partial[blockIdx.x * 3 + 2] = s[2];
+  }
+}
+__global__ void colsum3_final_kernel(const float* __restrict__ partial, int nb, float* __restrict__ db, int accumulate) {
+  const int j = threadIdx.x;
+  if (j < 3) {
+    double s = 0.0;
+    for (int i = 0; i < nb; ++i) s += (double)partial[i * 3 + j];
+    db[j] = (accumulate ? db[j] : 0.f) + (float)s;
+  }
+}
+}  // namespace
+
+extern "C" size_t lg_convT_s1_bwd_workspace_bytes(int B, int H, int W, int cb, int cs, int dtype) {
+  size_t a = lg_wgrad_workspace_bytes(B, H, W, cb, cs, dtype);
+  size_t b = 512 * 3 * sizeof(float);
+  return a > b ? a : b;
+}
+
+extern "C" int lg_convT_s1_tanh_bwd(const float* x, const float* dpre, const void* pack, float* dx, float* dw, float* db,
+                                    void* workspace, size_t ws_bytes, int B, int H, int W, int cb, int cs,
+                                    int accumulate, int dtype, void* stream) {
+  LG_CHECK_ARG(cb == 3, "lg_convT_s1_tanh_bwd: only image_channel == 3 is supported (got %d)", cb);
+  LG_CHECK_ARG(dpre && pack && workspace, "lg_convT_s1_tanh_bwd: null pointer");
+  LG_CHECK_ARG(ws_bytes >= lg_convT_s1_bwd_workspace_bytes(B, H, W, cb, cs, dtype),
+               "lg_convT_s1_tanh_bwd: workspace too small");
+  int rc;
+  if (dx) {  // dx[i,ci] = sum_k,co dpre[i+k-2,co] W[k,co,ci]  -> patch conv, stride 1, pad 2
+    rc = lg_conv_igemm(MODE_PATCH, dtype, dpre, pack, nullptr, dx, B, H, W, 3, cs, 0, 1, 2, stream);
+    if (rc) return rc;
+  }
+  if (dw) {
+    LG_CHECK_ARG(x, "lg_convT_s1_tanh_bwd: x is null but dw requested");
+    rc = lg_conv_wgrad(dpre, x, dw, workspace, ws_bytes, B, H, W, 3, cs, 1, 2, accumulate, dtype, stream);
+    if (rc) return rc;
+  }
+  if (db) {
+    const long long M = (long long)B * H * W;
+    LG_CHECK_ARG(M % 4 == 0, "lg_convT_s1_tanh_bwd: B*H*W must be a multiple of 4");
+    const long long n12 = M / 4;
+    int nb = (int)((n12 + 255) / 256);
+    if (nb > 512) nb = 512;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum3_kernel, dim3(nb), dim3(256), 0, st, dpre, (float*)workspace, n12);
+    LG_CHECK_LAUNCH("lg_convT_s1_tanh_bwd(bias)");
+    hipLaunchKernelGGL(colsum3_final_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, nb, db, accumulate);
+    LG_CHECK_LAUNCH("lg_convT_s1_tanh_bwd(bias final)");
+  }
+  return LG_OK;
+}

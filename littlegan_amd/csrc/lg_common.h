@@ -1,0 +1,87 @@
+// Shared device/host helpers for the LittleGAN gfx950 kernels.
+// Wavefront = 64, MFMA 32x32 tiles, LDS rows padded by 16 B (conflict-free ds_read_b128).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define LG_OK 0
+#define LG_ERR_ARG (-1)
+#define LG_ERR_LAUNCH (-2)
+#define LG_ERR_UNSUPPORTED (-3)
+
+#define LG_DT_F32 0
+#define LG_DT_BF16 1
+
+extern "C" void lg_set_error(const char* fmt, ...);
+
+#define LG_CHECK_ARG(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      lg_set_error(__VA_ARGS__);           \
+      return LG_ERR_ARG;                   \
+    }                                      \
+  } while (0)
+
+#define LG_CHECK_LAUNCH(name)                                              \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess) {                                               \
+      lg_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return LG_ERR_LAUNCH;                                                \
+    }                                                                      \
+  } while (0)
+
+// ---- XCD-aware bijective block remap (8 XCDs, blocks dealt round-robin) ----
+// Consecutive LOGICAL ids land on one XCD so neighbouring tiles share its L2.
+__device__ __forceinline__ int lg_xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+__device__ __forceinline__ float lg_leaky(float x, float a) { return x > 0.f ? x : a * x; }
+
+// wave64 sum via DPP/shuffles
+__device__ __forceinline__ float lg_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double lg_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum of NV floats (blockDim.x multiple of 64, <= 1024); result valid in thread 0.
+template <int NV>
+__device__ __forceinline__ void lg_block_sum(float (&v)[NV], float* smem /* >= NV*16 floats */) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = lg_wave_sum(v[i]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) smem[i * 16 + wid] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float s = 0.f;
+      for (int w = 0; w < nw; ++w) s += smem[i * 16 + w];
+      v[i] = s;
+    }
+  }
+}
+
+static inline int lg_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

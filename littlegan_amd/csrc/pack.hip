@@ -1,0 +1,80 @@
+// Weight packing: fp32 master kernels [5][5][Cb][Cs] (TF HWIO for Conv2D with Cb=in,Cs=out;
+// TF HWOI for Conv2DTranspose with Cb=out,Cs=in — /root/reference/model.py:15,39-40,86-87)
+// -> MFMA B-operand images [tap][Npad][K contiguous] in the compute dtype.
+//   down pack: n = Cs index, k = Cb index   (conv fwd / convT dgrad)      [25][npad(Cs)][Cb]
+//              Cb == 3: patch form [5][npad(Cs)][16], k = kx*3+c, k=15 zero
+//   up pack  : n = Cb index, k = Cs index   (convT fwd / conv dgrad)      [25][npad(Cb)][Cs]
+// One pack per layer per step (weights change every step); ~90 MB of traffic for the whole model.
+#include "lg_common.h"
+
+extern "C" int lg_npad(int n);
+
+namespace {
+
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ down, T* __restrict__ up, int Cb, int Cs,
+                            int npad_s, int npad_b, long long n_down, long long n_up) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_down + n_up; i += stride) {
+    if (i < n_down) {
+      float v = 0.f;
+      if (Cb == 3) {  // [5][npad_s][16]
+        const int j = (int)(i % 16);
+        const long long rem = i / 16;
+        const int n = (int)(rem % npad_s), ky = (int)(rem / npad_s);
+        if (j < 15 && n < Cs) v = w[((long long)(ky * 5 + j / 3) * 3 + (j % 3)) * Cs + n];
+      } else {  // [25][npad_s][Cb]
+        const int k = (int)(i % Cb);
+        const long long rem = i / Cb;
+        const int n = (int)(rem % npad_s), t = (int)(rem / npad_s);
+        if (n < Cs) v = w[((long long)t * Cb + k) * Cs + n];
+      }
+      down[i] = (T)v;
+    } else {  // [25][npad_b][Cs]
+      const long long u = i - n_down;
+      const int k = (int)(u % Cs);
+      const long long rem = u / Cs;
+      const int n = (int)(rem % npad_b), t = (int)(rem / npad_b);
+      float v = 0.f;
+      if (n < Cb) v = w[((long long)t * Cb + n) * Cs + k];
+      up[u] = (T)v;
+    }
+  }
+}
+
+inline long long down_elems(int cb, int cs) {
+  return cb == 3 ? 5ll * lg_npad(cs) * 16 : 25ll * lg_npad(cs) * cb;
+}
+inline long long up_elems(int cb, int cs) { return 25ll * lg_npad(cb) * cs; }
+
+}  // namespace
+
+// byte offset of the up pack inside a layer pack (down pack is at 0); both 256-B aligned
+extern "C" size_t lg_conv_pack_up_offset(int cb, int cs, int dtype) {
+  const size_t esz = dtype == LG_DT_F32 ? 4 : 2;
+  return (down_elems(cb, cs) * esz + 255) / 256 * 256;
+}
+
+extern "C" size_t lg_conv_pack_bytes(int cb, int cs, int dtype) {
+  const size_t esz = dtype == LG_DT_F32 ? 4 : 2;
+  return lg_conv_pack_up_offset(cb, cs, dtype) + (up_elems(cb, cs) * esz + 255) / 256 * 256;
+}
+
+extern "C" int lg_conv_pack(const float* w, void* pack, int cb, int cs, int dtype, void* stream) {
+  LG_CHECK_ARG(w && pack, "lg_conv_pack: null pointer");
+  LG_CHECK_ARG(cb > 0 && cs > 0 && (cb == 3 || cb % 32 == 0) && cs % 32 == 0,
+               "lg_conv_pack: unsupported channels cb=%d cs=%d", cb, cs);
+  LG_CHECK_ARG(dtype == LG_DT_F32 || dtype == LG_DT_BF16, "lg_conv_pack: bad dtype %d", dtype);
+  const long long nd = down_elems(cb, cs), nu = up_elems(cb, cs);
+  char* up = (char*)pack + lg_conv_pack_up_offset(cb, cs, dtype);
+  const int blocks = (int)((nd + nu + 255) / 256 < 4096 ? (nd + nu + 255) / 256 : 4096);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == LG_DT_F32)
+    hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, st, w, (float*)pack, (float*)up, cb, cs,
+                       lg_npad(cs), lg_npad(cb), nd, nu);
+  else
+    hipLaunchKernelGGL(pack_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, w, (__bf16*)pack, (__bf16*)up, cb, cs,
+                       lg_npad(cs), lg_npad(cb), nd, nu);
+  LG_CHECK_LAUNCH("lg_conv_pack");
+  return LG_OK;
+}

@@ -1,0 +1,396 @@
+// Weight-gradient contraction for the 5x5 stride-2 layers (and the 3-channel "patch" layers):
+//   dW[ky,kx,cb,cs] = sum_{n,y,x} big[n, 2y+ky-1, 2x+kx-1, cb] * small[n, y, x, cs]
+// big = the 2H-sized tensor (conv input x, or convT output-gradient), small = the H-sized one
+// (conv output-gradient, or convT input).  Same memory layout for tf Conv2D (HWIO) and
+// Conv2DTranspose (HWOI) kernels — /root/reference/model.py:15,39-40.
+// GEMM view per tap: M = Cb, N = Cs, K = pixels (B*Hm*Wm), split-K over blocks; each block writes
+// its own fp32 slab, a second kernel reduces slabs in fixed order (deterministic, no atomics).
+// Both operands are "k-major" in memory (pixel rows, channels contiguous) which is exactly the
+// v_mfma_f32_32x32x2_f32 operand shape: lane (r,h) reads LDS[pixel 2kk+h][channel r].
+// bf16 variant: LDS holds bf16 [pixel][channel]; fragments come from ds_read_b64_tr_b16.
+#include "lg_common.h"
+
+namespace {
+
+struct WgradParams {
+  const float* big;
+  const float* small;
+  float* slab;
+  int B, Hm, Wm, Cb, Cs, M;
+  int Cbp;       // slab rows per tap (Cb, or 16 in patch mode)
+  int chunk;     // pixels per split, multiple of KP
+  int nti, ntj, ntaps;
+  int pstride, ppad;
+};
+
+template <bool BF16, bool PATCH, int WI, int WJ, int MT, int NT>
+__global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p) {
+  constexpr int NTHR = 64 * WI * WJ;
+  constexpr int BI = WI * MT * 32, BJ = WJ * NT * 32;
+  constexpr int KP = BF16 ? 64 : 32;           // pixels per k tile
+  constexpr int ESZ = BF16 ? 2 : 4;
+  constexpr int RSA = BI * ESZ + (BF16 ? 16 : 0);   // LDS row strides (bytes)
+  constexpr int RSB = BJ * ESZ + (BF16 ? 16 : 0);
+  constexpr int LA = BI / 4, LB = BJ / 4;      // float4 lanes per row
+  static_assert(NTHR % LA == 0 && NTHR % LB == 0, "staging geometry");
+  constexpr int RA = NTHR / LA, RB = NTHR / LB;  // rows per pass
+  constexpr int PA = KP / RA, PB = KP / RB;
+  static_assert(PA >= 1 && PB >= 1 && KP % RA == 0 && KP % RB == 0, "staging geometry");
+  constexpr int A_BYTES = KP * RSA, B_BYTES = KP * RSB;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA0 = smem;
+  char* sB0 = smem + 2 * A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wi = wid / WJ, wj = wid % WJ;
+
+  int bx = blockIdx.x;
+  const int tj = bx % p.ntj; bx /= p.ntj;
+  const int ti = bx % p.nti; bx /= p.nti;
+  const int t = bx;  // tap
+  const int ky = PATCH ? t : t / 5, kx = PATCH ? 0 : t - (t / 5) * 5;
+  const int i0 = ti * BI, j0 = tj * BJ;
+  const int split = blockIdx.y;
+  const int kbeg = split * p.chunk;
+  const int kend = min(kbeg + p.chunk, p.M);
+  const int nk = (kend - kbeg + KP - 1) / KP;
+  const int HWm = p.Hm * p.Wm;
+  const int Hb = (PATCH ? p.pstride : 2) * p.Hm, Wb = (PATCH ? p.pstride : 2) * p.Wm;
+
+  const int arow = tid / LA, alc = tid % LA;
+  const int brow = tid / LB, blc = tid % LB;
+  f32x4 ra[PA], rb[PB];
+
+  auto load_tile = [&](int it) {
+    const int k0 = kbeg + it * KP;
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      const int m = k0 + q * RA + arow;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < kend) {
+        const int n = m / HWm, rem = m - n * HWm;
+        const int y = rem / p.Wm, x = rem - y * p.Wm;
+        if constexpr (PATCH) {
+          const int sy = p.pstride * y + ky - p.ppad;
+          if ((unsigned)sy < (unsigned)Hb) {
+            const int sx0 = p.pstride * x - p.ppad;
+            const float* base = p.big + ((long long)(n * Hb + sy) * Wb) * 3;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int j = alc * 4 + e;
+              const int sx = sx0 + j / 3;
+              if (j < 15 && (unsigned)sx < (unsigned)Wb) v[e] = base[sx0 * 3 + j];
+            }
+          }
+        } else {
+          const int sy = 2 * y + ky - 1, sx = 2 * x + kx - 1;
+          if ((unsigned)sy < (unsigned)Hb && (unsigned)sx < (unsigned)Wb)
+            v = *reinterpret_cast<const f32x4*>(p.big + ((long long)(n * Hb + sy) * Wb + sx) * p.Cb + i0 + alc * 4);
+        }
+      }
+      ra[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      const int m = k0 + q * RB + brow;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < kend) v = *reinterpret_cast<const f32x4*>(p.small + (long long)m * p.Cs + j0 + blc * 4);
+      rb[q] = v;
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    char* sA = sA0 + buf * A_BYTES;
+    char* sB = sB0 + buf * B_BYTES;
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      char* d = sA + (q * RA + arow) * RSA;
+      if constexpr (BF16) {
+        bf16x4 w;
+        w[0] = (__bf16)ra[q][0]; w[1] = (__bf16)ra[q][1]; w[2] = (__bf16)ra[q][2]; w[3] = (__bf16)ra[q][3];
+        *reinterpret_cast<bf16x4*>(d + alc * 8) = w;
+      } else {
+        *reinterpret_cast<f32x4*>(d + alc * 16) = ra[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      char* d = sB + (q * RB + brow) * RSB;
+      if constexpr (BF16) {
+        bf16x4 w;
+        w[0] = (__bf16)rb[q][0]; w[1] = (__bf16)rb[q][1]; w[2] = (__bf16)rb[q][2]; w[3] = (__bf16)rb[q][3];
+        *reinterpret_cast<bf16x4*>(d + blc * 8) = w;
+      } else {
+        *reinterpret_cast<f32x4*>(d + blc * 16) = rb[q];
+      }
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (nk > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int it = 0; it < nk; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nk) load_tile(it + 1);
+    const char* sA = sA0 + buf * A_BYTES;
+    const char* sB = sB0 + buf * B_BYTES;
+    if constexpr (!BF16) {
+      const float* fa = reinterpret_cast<const float*>(sA) + wi * MT * 32 + r;
+      const float* fb = reinterpret_cast<const float*>(sB) + wj * NT * 32 + r;
+#pragma unroll 4
+      for (int kk = 0; kk < KP / 2; ++kk) {
+        const int pix = 2 * kk + h;
+        float a[MT], b[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = fa[pix * BI + i * 32];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = fb[pix * BJ + j * 32];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3
+      // of a 4(row) x 16(col) block and receives column (lane&15) of the 4 rows.  For the 32x32x16 MFMA
+      // lane (r,h) needs channel r at pixels 8h..8h+7 of the 16-pixel k step: two blocks (rows 8h..8h+3,
+      // 8h+4..8h+7), columns 16*(r>>4) .. +15.
+      const int g = lane >> 4;           // 16-lane group: (g&1) = channel half, (g>>1) = h
+      const int lq = (lane & 15) >> 2, lp = lane & 3;
+      const int colbase = 16 * (g & 1) + 4 * lp;
+#pragma unroll
+      for (int ks = 0; ks < KP / 16; ++ks) {
+        const int row0 = ks * 16 + 8 * (g >> 1) + lq;
+        bf16x8 a[MT], b[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const char* pa = sA + row0 * RSA + ((wi * MT + i) * 32 + colbase) * 2;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa + 4 * RSA));
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          a[i] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const char* pb = sB + row0 * RSB + ((wj * NT + j) * 32 + colbase) * 2;
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb + 4 * RSB));
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          b[j] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (it + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // slab[split][t][i][j]
+  float* out = p.slab + ((long long)split * p.ntaps + t) * p.Cbp * p.Cs;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = j0 + (wj * NT + j) * 32 + r;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = i0 + (wi * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < p.Cbp && col < p.Cs) out[(long long)row * p.Cs + col] = acc[i][j][e];
+      }
+    }
+  }
+}
+
+// out[t][i<rows_v][j] (+)= sum_s slab[s][t][i][j]  (slab rows_p >= rows_v per tap)
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int nsplit, int ntaps,
+                                   int rows_p, int rows_v, int cols, int accumulate) {
+  const long long n_out = (long long)ntaps * rows_v * cols;
+  const long long slab_sz = (long long)ntaps * rows_p * cols;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += stride) {
+    const int j = (int)(o % cols);
+    const long long rem = o / cols;
+    const int i = (int)(rem % rows_v), t = (int)(rem / rows_v);
+    const long long si = ((long long)t * rows_p + i) * cols + j;
+    float s = accumulate ? out[o] : 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[k * slab_sz + si];
+    out[o] = s;
+  }
+}
+
+// column sums of a [M][C] matrix: partial[blk][C]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                     long long M, int C, long long rows_per_blk) {
+  const int c4 = C / 4;                 // C % 4 == 0
+  const int tpc = 256 / c4 > 0 ? 256 / c4 : 1;  // threads per column-quad along rows
+  const long long r0 = (long long)blockIdx.x * rows_per_blk;
+  const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
+  __shared__ f32x4 sred[256];
+  for (int cq0 = 0; cq0 < c4; cq0 += 256) {
+    const int cq = cq0 + (c4 >= 256 ? threadIdx.x : threadIdx.x % c4);
+    const int rr = c4 >= 256 ? 0 : threadIdx.x / c4;
+    const int nr = c4 >= 256 ? 1 : tpc;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (cq < c4 && rr < nr)
+      for (long long m = r0 + rr; m < r1; m += nr) s += *reinterpret_cast<const f32x4*>(x + m * C + cq * 4);
+    sred[threadIdx.x] = s;
+    __syncthreads();
+    if (rr == 0 && cq < c4) {
+      for (int k = 1; k < nr; ++k)
+        if (threadIdx.x + k * c4 < 256) s += sred[threadIdx.x + k * c4];
+      *reinterpret_cast<f32x4*>(partial + (long long)blockIdx.x * C + cq * 4) = s;
+    }
+    __syncthreads();
+  }
+}
+
+template <bool BF16, bool PATCH, int WI, int WJ, int MT, int NT>
+void launch_wgrad(WgradParams p, int nsplit, hipStream_t st) {
+  constexpr int BI = WI * MT * 32, BJ = WJ * NT * 32, KP = BF16 ? 64 : 32, ESZ = BF16 ? 2 : 4;
+  constexpr int RSA = BI * ESZ + (BF16 ? 16 : 0), RSB = BJ * ESZ + (BF16 ? 16 : 0);
+  const size_t lds = 2 * (size_t)KP * (RSA + RSB);
+  p.nti = lg_cdiv(p.Cbp, BI);
+  p.ntj = lg_cdiv(p.Cs, BJ);
+  auto kern = wgrad_kernel<BF16, PATCH, WI, WJ, MT, NT>;
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(p.nti * p.ntj * p.ntaps, nsplit);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WI * WJ), lds, st, p);
+}
+
+struct TileSel { int bi, bj; };
+inline TileSel pick_tile(int cbp, int cs) {
+  TileSel s;
+  s.bi = cbp % 128 == 0 ? 128 : (cbp % 64 == 0 ? 64 : 32);
+  s.bj = cs % 128 == 0 ? 128 : (cs % 64 == 0 ? 64 : 32);
+  if (s.bi == 64 && s.bj == 64) { /* 2x2 waves of 32x32 */ }
+  return s;
+}
+
+inline int pick_nsplit(int tiles, int M, int KP) {
+  int ns = (1024 + tiles - 1) / tiles;
+  const int maxs = M / (4 * KP) > 0 ? M / (4 * KP) : 1;
+  if (ns > maxs) ns = maxs;
+  if (ns < 1) ns = 1;
+  if (ns > 256) ns = 256;
+  return ns;
+}
+
+}  // namespace
+
+extern "C" size_t lg_wgrad_workspace_bytes(int B, int Hm, int Wm, int cb, int cs, int dtype) {
+  const int KP = dtype == LG_DT_BF16 ? 64 : 32;
+  const int cbp = cb == 3 ? 16 : cb, ntaps = cb == 3 ? 5 : 25;
+  TileSel ts = pick_tile(cb == 3 ? 32 : cbp, cs);
+  const int tiles = lg_cdiv(cbp, ts.bi) * lg_cdiv(cs, ts.bj) * ntaps;
+  const int ns = pick_nsplit(tiles, B * Hm * Wm, KP);
+  return (size_t)ns * ntaps * cbp * cs * sizeof(float);
+}
+
+// dW[5][5][cb][cs] (+)= big (x) small ; big [B,s*Hm,s*Wm,cb], small [B,Hm,Wm,cs].
+// cb == 3 selects the patch form with source stride `pstride` and pad-before `ppad`
+// (conv1: 2,1 ; stride-1 final layer: 1,2); otherwise stride 2 / pad 1.
+extern "C" int lg_conv_wgrad(const float* big, const float* small, float* dw, void* workspace, size_t ws_bytes,
+                             int B, int Hm, int Wm, int cb, int cs, int pstride, int ppad, int accumulate, int dtype,
+                             void* stream) {
+  LG_CHECK_ARG(big && small && dw && workspace, "lg_conv_wgrad: null pointer");
+  LG_CHECK_ARG(B > 0 && Hm > 0 && Wm > 0 && cs % 32 == 0 && (cb == 3 || cb % 32 == 0),
+               "lg_conv_wgrad: bad shape B=%d Hm=%d Wm=%d cb=%d cs=%d", B, Hm, Wm, cb, cs);
+  LG_CHECK_ARG(ws_bytes >= lg_wgrad_workspace_bytes(B, Hm, Wm, cb, cs, dtype), "lg_conv_wgrad: workspace too small");
+  const bool patch = cb == 3;
+  const bool bf16 = dtype == LG_DT_BF16 && !patch;  // patch layers stay on the exact f32 MFMA
+  const int KP = bf16 ? 64 : 32;
+  WgradParams p{};
+  p.big = big; p.small = small; p.slab = (float*)workspace;
+  p.B = B; p.Hm = Hm; p.Wm = Wm; p.Cb = cb; p.Cs = cs; p.M = B * Hm * Wm;
+  p.Cbp = patch ? 16 : cb; p.ntaps = patch ? 5 : 25; p.pstride = pstride; p.ppad = ppad;
+  TileSel ts = pick_tile(patch ? 32 : p.Cbp, cs);
+  const int tiles = lg_cdiv(p.Cbp, ts.bi) * lg_cdiv(cs, ts.bj) * p.ntaps;
+  const int KPws = dtype == LG_DT_BF16 ? 64 : 32;  // workspace sized with the caller's dtype
+  int ns = pick_nsplit(tiles, p.M, KPws);
+  p.chunk = (lg_cdiv(p.M, ns) + KP - 1) / KP * KP;
+  ns = lg_cdiv(p.M, p.chunk);
+  hipStream_t st = (hipStream_t)stream;
+#define LG_WG(BF, PT, WI, WJ, MT, NT) launch_wgrad<BF, PT, WI, WJ, MT, NT>(p, ns, st)
+  if (patch) {
+    if (ts.bj == 128) LG_WG(false, true, 1, 2, 1, 2); else if (ts.bj == 64) LG_WG(false, true, 1, 2, 1, 1); else LG_WG(false, true, 1, 1, 1, 1);
+  } else if (!bf16) {
+    if (ts.bi == 128 && ts.bj == 128) LG_WG(false, false, 2, 2, 2, 2);
+    else if (ts.bi == 128 && ts.bj == 64) LG_WG(false, false, 2, 2, 2, 1);
+    else if (ts.bi == 128) LG_WG(false, false, 4, 1, 1, 1);
+    else if (ts.bi == 64 && ts.bj == 128) LG_WG(false, false, 2, 2, 1, 2);
+    else if (ts.bi == 64 && ts.bj == 64) LG_WG(false, false, 2, 2, 1, 1);
+    else if (ts.bi == 64) LG_WG(false, false, 2, 1, 1, 1);
+    else if (ts.bj == 128) LG_WG(false, false, 1, 2, 1, 2);
+    else if (ts.bj == 64) LG_WG(false, false, 1, 2, 1, 1);
+    else LG_WG(false, false, 1, 1, 1, 1);
+  } else {
+    if (ts.bi == 128 && ts.bj == 128) LG_WG(true, false, 2, 2, 2, 2);
+    else if (ts.bi == 128 && ts.bj == 64) LG_WG(true, false, 2, 2, 2, 1);
+    else if (ts.bi == 128) LG_WG(true, false, 4, 1, 1, 1);
+    else if (ts.bi == 64 && ts.bj == 128) LG_WG(true, false, 2, 2, 1, 2);
+    else if (ts.bi == 64 && ts.bj == 64) LG_WG(true, false, 2, 2, 1, 1);
+    else if (ts.bi == 64) LG_WG(true, false, 2, 1, 1, 1);
+    else if (ts.bj == 128) LG_WG(true, false, 1, 2, 1, 2);
+    else if (ts.bj == 64) LG_WG(true, false, 1, 2, 1, 1);
+    else LG_WG(true, false, 1, 1, 1, 1);
+  }
+#undef LG_WG
+  LG_CHECK_LAUNCH("lg_conv_wgrad");
+  const int rows_v = patch ? 15 : cb;
+  const long long n_out = (long long)p.ntaps * rows_v * cs;
+  const int rblocks = (int)((n_out + 255) / 256 < 2048 ? (n_out + 255) / 256 : 2048);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(rblocks), dim3(256), 0, st, (const float*)workspace, dw, ns, p.ntaps,
+                     p.Cbp, rows_v, cs, accumulate);
+  LG_CHECK_LAUNCH("lg_conv_wgrad(reduce)");
+  return LG_OK;
+}
+
+extern "C" size_t lg_bias_grad_workspace_bytes(long long M, int C) {
+  long long nb = (M + 255) / 256;
+  if (nb > 512) nb = 512;
+  return (size_t)nb * C * sizeof(float);
+}
+
+// db[C] (+)= column sums of dy[M][C]
+extern "C" int lg_bias_grad(const float* dy, float* db, void* workspace, size_t ws_bytes, long long M, int C,
+                            int accumulate, void* stream) {
+  LG_CHECK_ARG(dy && db && workspace, "lg_bias_grad: null pointer");
+  LG_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 4096, "lg_bias_grad: bad shape M=%lld C=%d", M, C);
+  LG_CHECK_ARG(ws_bytes >= lg_bias_grad_workspace_bytes(M, C), "lg_bias_grad: workspace too small");
+  long long nb = (M + 255) / 256;
+  if (nb > 512) nb = 512;
+  const long long rpb = (M + nb - 1) / nb;
+  nb = (M + rpb - 1) / rpb;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_kernel, dim3((int)nb), dim3(256), 0, st, dy, (float*)workspace, M, C, rpb);
+  LG_CHECK_LAUNCH("lg_bias_grad");
+  const int rblocks = (C + 255) / 256;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(rblocks), dim3(256), 0, st, (const float*)workspace, db, (int)nb, 1, 1, 1,
+                     C, accumulate);
+  LG_CHECK_LAUNCH("lg_bias_grad(reduce)");
+  return LG_OK;
+}

@@ -1,0 +1,318 @@
+"""torch-tensor front end of the C ABI (include/littlegan_hip.h).
+
+PyTorch here is plumbing only: it owns device memory and the HIP stream.  Every function
+validates shapes on the host (a wrong shape must never reach a hand-written kernel), then
+enqueues the HIP kernels on torch's current stream.  No fallback paths.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import DT_BF16, DT_F32, check
+
+_WS = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t, shape=None, name="tensor"):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{name}: need a contiguous fp32 CUDA tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: shape {tuple(t.shape)} != expected {tuple(shape)}")
+    return t
+
+
+def workspace(nbytes: int, device, tag="default") -> torch.Tensor:
+    """Grow-only scratch buffer per (device, tag); kernels on one stream run in order so sharing is safe."""
+    key = (str(device), tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------ conv layers
+def conv_pack_bytes(cb, cs, dtype):
+    return int(_lib.load().lg_conv_pack_bytes(cb, cs, dtype))
+
+
+def conv_pack(w, cb, cs, dtype, out=None):
+    """w: master kernel [5,5,cb,cs] -> packed MFMA operand images (uint8 buffer)."""
+    _chk(w, (5, 5, cb, cs), "w")
+    if out is None:
+        out = torch.empty(conv_pack_bytes(cb, cs, dtype), dtype=torch.uint8, device=w.device)
+    check(_lib.load().lg_conv_pack(_p(w), _p(out), cb, cs, dtype, _stream()), "lg_conv_pack")
+    return out
+
+
+def conv2d_s2_fwd(x, pack, bias, cs, dtype, out=None):
+    B, H, W, cb = x.shape
+    _chk(x, name="x")
+    if H % 2 or W % 2:
+        raise ValueError("conv2d_s2_fwd: H and W must be even")
+    if out is None:
+        out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.float32, device=x.device)
+    _chk(out, (B, H // 2, W // 2, cs), "out")
+    if bias is not None:
+        _chk(bias, (cs,), "bias")
+    check(_lib.load().lg_conv2d_s2_fwd(_p(x), _p(pack), _p(bias), _p(out), B, H // 2, W // 2, cb, cs, dtype, _stream()),
+          "lg_conv2d_s2_fwd")
+    return out
+
+
+def conv2d_s2_dgrad(dy, pack, cb, dtype, out=None):
+    B, Hs, Ws, cs = dy.shape
+    _chk(dy, name="dy")
+    if out is None:
+        out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.float32, device=dy.device)
+    _chk(out, (B, 2 * Hs, 2 * Ws, cb), "out")
+    check(_lib.load().lg_conv2d_s2_dgrad(_p(dy), _p(pack), _p(out), B, Hs, Ws, cb, cs, dtype, _stream()),
+          "lg_conv2d_s2_dgrad")
+    return out
+
+
+def _wgrad(fn_name, big, small, dw, accumulate, dtype, swap):
+    lib = _lib.load()
+    B, Hs, Ws, cs = small.shape
+    cb = big.shape[3]
+    _chk(big, (B, 2 * Hs, 2 * Ws, cb), "big")
+    _chk(small, name="small")
+    _chk(dw, (5, 5, cb, cs), "dw")
+    nbytes = int(lib.lg_wgrad_workspace_bytes(B, Hs, Ws, cb, cs, dtype))
+    ws = workspace(nbytes, big.device, "wgrad")
+    a, b = (small, big) if swap else (big, small)
+    check(getattr(lib, fn_name)(_p(a), _p(b), _p(dw), _p(ws), ws.numel(), B, Hs, Ws, cb, cs, int(accumulate), dtype,
+                                _stream()), fn_name)
+    return dw
+
+
+def conv2d_s2_wgrad(x, dy, dw, accumulate, dtype):
+    """dw[5,5,cb,cs] (+)= wgrad(x [B,2Hs,2Ws,cb], dy [B,Hs,Ws,cs])"""
+    return _wgrad("lg_conv2d_s2_wgrad", x, dy, dw, accumulate, dtype, swap=False)
+
+
+def convT_s2_fwd(x, pack, bias, cb, dtype, out=None):
+    B, Hs, Ws, cs = x.shape
+    _chk(x, name="x")
+    if out is None:
+        out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.float32, device=x.device)
+    _chk(out, (B, 2 * Hs, 2 * Ws, cb), "out")
+    if bias is not None:
+        _chk(bias, (cb,), "bias")
+    check(_lib.load().lg_convT_s2_fwd(_p(x), _p(pack), _p(bias), _p(out), B, Hs, Ws, cb, cs, dtype, _stream()),
+          "lg_convT_s2_fwd")
+    return out
+
+
+def convT_s2_dgrad(dy, pack, cs, dtype, out=None):
+    B, H, W, cb = dy.shape
+    _chk(dy, name="dy")
+    if out is None:
+        out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.float32, device=dy.device)
+    _chk(out, (B, H // 2, W // 2, cs), "out")
+    check(_lib.load().lg_convT_s2_dgrad(_p(dy), _p(pack), _p(out), B, H // 2, W // 2, cb, cs, dtype, _stream()),
+          "lg_convT_s2_dgrad")
+    return out
+
+
+def convT_s2_wgrad(x, dy, dw, accumulate, dtype):
+    """dw[5,5,cb,cs] (+)= wgrad(x [B,Hs,Ws,cs], dy [B,2Hs,2Ws,cb])"""
+    return _wgrad("lg_convT_s2_wgrad", dy, x, dw, accumulate, dtype, swap=True)
+
+
+def convT_s1_tanh_fwd(x, pack, bias, cb, dtype, out=None):
+    B, H, W, cs = x.shape
+    _chk(x, name="x")
+    if out is None:
+        out = torch.empty(B, H, W, cb, dtype=torch.float32, device=x.device)
+    _chk(out, (B, H, W, cb), "out")
+    _chk(bias, (cb,), "bias")
+    check(_lib.load().lg_convT_s1_tanh_fwd(_p(x), _p(pack), _p(bias), _p(out), B, H, W, cb, cs, dtype, _stream()),
+          "lg_convT_s1_tanh_fwd")
+    return out
+
+
+def convT_s1_tanh_bwd(x, dpre, pack, cs, dtype, dx=None, dw=None, db=None, accumulate=False):
+    lib = _lib.load()
+    B, H, W, cb = dpre.shape
+    _chk(dpre, name="dpre")
+    if x is not None:
+        _chk(x, (B, H, W, cs), "x")
+    if dx is not None:
+        _chk(dx, (B, H, W, cs), "dx")
+    if dw is not None:
+        _chk(dw, (5, 5, cb, cs), "dw")
+    if db is not None:
+        _chk(db, (cb,), "db")
+    nbytes = int(lib.lg_convT_s1_bwd_workspace_bytes(B, H, W, cb, cs, dtype))
+    ws = workspace(nbytes, dpre.device, "wgrad")
+    check(lib.lg_convT_s1_tanh_bwd(_p(x), _p(dpre), _p(pack), _p(dx), _p(dw), _p(db), _p(ws), ws.numel(), B, H, W, cb,
+                                   cs, int(accumulate), dtype, _stream()), "lg_convT_s1_tanh_bwd")
+    return dx
+
+
+def bias_grad(dy, db, accumulate=False):
+    C = dy.shape[-1]
+    M = dy.numel() // C
+    _chk(dy, name="dy")
+    _chk(db, (C,), "db")
+    lib = _lib.load()
+    ws = workspace(int(lib.lg_bias_grad_workspace_bytes(M, C)), dy.device, "small")
+    check(lib.lg_bias_grad(_p(dy), _p(db), _p(ws), ws.numel(), M, C, int(accumulate), _stream()), "lg_bias_grad")
+    return db
+
+
+# ------------------------------------------------------------------ instance norm
+def instnorm_stats(x, gamma, beta, pre_leaky, alpha, stats=None):
+    B = x.shape[0]
+    Ln = x.numel() // B
+    _chk(x, name="x")
+    if stats is None:
+        stats = torch.empty(B, 4, dtype=torch.float32, device=x.device)
+    _chk(stats, (B, 4), "stats")
+    lib = _lib.load()
+    ws = workspace(int(lib.lg_instnorm_workspace_bytes(B, Ln)), x.device, "small")
+    check(lib.lg_instnorm_leaky_stats(_p(x), _p(stats), _p(gamma), _p(beta), _p(ws), ws.numel(), B, Ln, int(pre_leaky),
+                                      float(alpha), _stream()), "lg_instnorm_leaky_stats")
+    return stats
+
+
+def instnorm_apply(x, stats, skip, pre_leaky, post_leaky, alpha, out=None):
+    B = x.shape[0]
+    Ln = x.numel() // B
+    _chk(x, name="x")
+    _chk(stats, (B, 4), "stats")
+    if skip is not None:
+        _chk(skip, name="skip")
+        if skip.numel() != x.numel():
+            raise ValueError("instnorm_apply: skip has a different size")
+    if out is None:
+        out = torch.empty_like(x)
+    _chk(out, x.shape, "out")
+    check(_lib.load().lg_instnorm_leaky_apply(_p(x), _p(stats), _p(skip), _p(out), B, Ln, int(pre_leaky),
+                                              int(post_leaky), float(alpha), _stream()), "lg_instnorm_leaky_apply")
+    return out
+
+
+def instnorm_bwd(x, stats, g, dgamma, dbeta, pre_leaky, post_leaky, alpha, accumulate=False, out=None):
+    B = x.shape[0]
+    Ln = x.numel() // B
+    _chk(x, name="x")
+    _chk(g, name="g")
+    if g.numel() != x.numel():
+        raise ValueError("instnorm_bwd: g has a different size")
+    _chk(stats, (B, 4), "stats")
+    if out is None:
+        out = torch.empty_like(x)
+    _chk(out, x.shape, "out")
+    lib = _lib.load()
+    ws = workspace(int(lib.lg_instnorm_workspace_bytes(B, Ln)), x.device, "small")
+    check(lib.lg_instnorm_leaky_bwd(_p(x), _p(stats), _p(g), _p(out), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), B, Ln,
+                                    int(pre_leaky), int(post_leaky), float(alpha), int(accumulate), _stream()),
+          "lg_instnorm_leaky_bwd")
+    return out
+
+
+# ------------------------------------------------------------------ dense
+def dense_fwd(x, w, bias, out=None):
+    B, K = x.shape
+    N = w.shape[1]
+    _chk(x, name="x")
+    _chk(w, (K, N), "w")
+    if out is None:
+        out = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    _chk(out, (B, N), "out")
+    check(_lib.load().lg_dense_fwd(_p(x), _p(w), _p(bias), _p(out), B, K, N, _stream()), "lg_dense_fwd")
+    return out
+
+
+def dense_wgrad(x, dy, dw, db, accumulate=False):
+    B, K = x.shape
+    N = dy.shape[1]
+    _chk(x, name="x")
+    _chk(dy, (B, N), "dy")
+    _chk(dw, (K, N), "dw")
+    check(_lib.load().lg_dense_wgrad(_p(x), _p(dy), _p(dw), _p(db), B, K, N, int(accumulate), _stream()),
+          "lg_dense_wgrad")
+
+
+def heads_fwd(x, wpr, bpr, wc, bc, out=None):
+    B, K = x.shape
+    c = wc.shape[1]
+    _chk(x, name="x")
+    _chk(wpr, (K, 1), "wpr")
+    _chk(wc, (K, c), "wc")
+    if out is None:
+        out = torch.empty(B, 1 + c, dtype=torch.float32, device=x.device)
+    _chk(out, (B, 1 + c), "out")
+    check(_lib.load().lg_heads_fwd(_p(x), _p(wpr), _p(bpr), _p(wc), _p(bc), _p(out), B, K, c, _stream()), "lg_heads_fwd")
+    return out
+
+
+def heads_dgrad(dz, wpr, wc, out=None):
+    B = dz.shape[0]
+    K, c = wc.shape
+    _chk(dz, (B, 1 + c), "dz")
+    if out is None:
+        out = torch.empty(B, K, dtype=torch.float32, device=dz.device)
+    _chk(out, (B, K), "out")
+    check(_lib.load().lg_heads_dgrad(_p(dz), _p(wpr), _p(wc), _p(out), B, K, c, _stream()), "lg_heads_dgrad")
+    return out
+
+
+def heads_wgrad(x, dz, dwpr, dbpr, dwc, dbc, accumulate=False):
+    B, K = x.shape
+    c = dwc.shape[1]
+    _chk(x, name="x")
+    _chk(dz, (B, 1 + c), "dz")
+    _chk(dwpr, (K, 1), "dwpr")
+    _chk(dwc, (K, c), "dwc")
+    check(_lib.load().lg_heads_wgrad(_p(x), _p(dz), _p(dwpr), _p(dbpr), _p(dwc), _p(dbc), B, K, c, int(accumulate),
+                                     _stream()), "lg_heads_wgrad")
+
+
+# ------------------------------------------------------------------ losses / optimizer
+def bce_heads_loss(p, t_c, t_pr, w_pr, w_c, loss, dz, accumulate):
+    B, J = p.shape
+    _chk(p, name="p")
+    _chk(dz, (B, J), "dz")
+    if t_c is not None:
+        _chk(t_c, (B, J - 1), "t_c")
+    check(_lib.load().lg_bce_heads_loss_fwd_bwd(_p(p), _p(t_c), float(t_pr), float(w_pr), float(w_c), _p(loss), _p(dz),
+                                                B, J - 1, int(accumulate), _stream()), "lg_bce_heads_loss_fwd_bwd")
+
+
+def l1_tanh_loss(t, img, g_in, dpre, loss, lam, accumulate):
+    _chk(t, name="t")
+    _chk(img, t.shape, "img")
+    if g_in is not None:
+        _chk(g_in, t.shape, "g_in")
+    if dpre is not None:
+        _chk(dpre, t.shape, "dpre")
+    lib = _lib.load()
+    ws = workspace(int(lib.lg_l1_workspace_bytes()), t.device, "small")
+    check(lib.lg_l1_tanh_loss_fwd_bwd(_p(t), _p(img), _p(g_in), _p(dpre), _p(loss), _p(ws), ws.numel(), t.numel(),
+                                      float(lam), int(accumulate), _stream()), "lg_l1_tanh_loss_fwd_bwd")
+
+
+def clip_adam_update(w, g, m, v, state, lr, b1, b2, eps, clip, gscale=1.0):
+    n = w.numel()
+    for t, nm in ((w, "w"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, name=nm)
+        if t.numel() != n:
+            raise ValueError("clip_adam_update: size mismatch")
+    check(_lib.load().lg_clip_adam_update(_p(w), _p(g), _p(m), _p(v), n, _p(state), float(lr), float(b1), float(b2),
+                                          float(eps), float(clip), float(gscale), _stream()), "lg_clip_adam_update")
+
+
+def adam_advance(state, b1, b2):
+    check(_lib.load().lg_adam_advance(_p(state), float(b1), float(b2), _stream()), "lg_adam_advance")

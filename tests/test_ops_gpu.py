@@ -1,0 +1,226 @@
+"""Per-op parity: every C-ABI entry point vs the fp64 numpy oracle on the same seeded inputs.
+Tolerances (max-abs error relative to max-abs of the oracle result):
+  f32 path  (exact-f32 MFMA, f32 accumulate)         : 3e-5
+  bf16 path (bf16 operands, f32 accumulate)           : 2e-2   (operand rounding 2^-8 per factor)
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 3e-5, 1: 2e-2}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from littlegan_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
+
+
+def rel(got, exp):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got)
+    return np.abs(got - exp).max() / (np.abs(exp).max() + 1e-30)
+
+
+def r32(rng, *shape, scale=1.0):
+    """random values exactly representable in f32 (so the f32 kernels see the oracle's inputs)"""
+    return (rng.standard_normal(shape) * scale).astype(np.float32).astype(np.float64)
+
+
+S2_CASES = [  # (B, Hs, Ws, cb, cs)
+    (3, 5, 6, 32, 64), (2, 8, 9, 64, 128), (2, 4, 4, 128, 32), (2, 3, 3, 256, 384), (3, 7, 5, 3, 64), (2, 6, 6, 3, 32),
+    (1, 16, 16, 32, 32),
+]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", S2_CASES)
+def test_conv2d_s2_fwd_dgrad_wgrad(ops, case, dtype):
+    B, Hs, Ws, cb, cs = case
+    rng = np.random.default_rng(hash(case) % 2**31)
+    x = r32(rng, B, 2 * Hs, 2 * Ws, cb)
+    w = r32(rng, 5, 5, cb, cs, scale=0.1)
+    b = r32(rng, cs)
+    dy = r32(rng, B, Hs, Ws, cs)
+    pack = ops.conv_pack(dev(w), cb, cs, dtype)
+    y = ops.conv2d_s2_fwd(dev(x), pack, dev(b), cs, dtype)
+    assert rel(y, O.conv2d(x, w, b, 2)) < TOL[dtype]
+    dx_e, dw_e, db_e = O.conv2d_bwd(x, w, dy, 2)
+    dx = ops.conv2d_s2_dgrad(dev(dy), pack, cb, dtype)
+    assert rel(dx, dx_e) < TOL[dtype]
+    dw = torch.full((5, 5, cb, cs), 7.0, device="cuda")
+    ops.conv2d_s2_wgrad(dev(x), dev(dy), dw, False, dtype)
+    assert rel(dw, dw_e) < TOL[dtype]
+    ops.conv2d_s2_wgrad(dev(x), dev(dy), dw, True, dtype)  # accumulate
+    assert rel(dw, 2 * dw_e) < TOL[dtype]
+    db = torch.empty(cs, device="cuda")
+    ops.bias_grad(dev(dy), db)
+    assert rel(db, db_e) < 3e-5
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", [c for c in S2_CASES if c[3] != 3])
+def test_convT_s2_fwd_dgrad_wgrad(ops, case, dtype):
+    B, Hs, Ws, cb, cs = case
+    rng = np.random.default_rng(hash(case) % 2**31 + 1)
+    x = r32(rng, B, Hs, Ws, cs)
+    w = r32(rng, 5, 5, cb, cs, scale=0.1)  # HWOI: out=cb, in=cs
+    b = r32(rng, cb)
+    dy = r32(rng, B, 2 * Hs, 2 * Ws, cb)
+    pack = ops.conv_pack(dev(w), cb, cs, dtype)
+    y = ops.convT_s2_fwd(dev(x), pack, dev(b), cb, dtype)
+    assert rel(y, O.conv2d_transpose(x, w, b, 2)) < TOL[dtype]
+    dx_e, dw_e, db_e = O.conv2d_transpose_bwd(x, w, dy, 2)
+    dx = ops.convT_s2_dgrad(dev(dy), pack, cs, dtype)
+    assert rel(dx, dx_e) < TOL[dtype]
+    dw = torch.zeros(5, 5, cb, cs, device="cuda")
+    ops.convT_s2_wgrad(dev(x), dev(dy), dw, False, dtype)
+    assert rel(dw, dw_e) < TOL[dtype]
+    db = torch.empty(cb, device="cuda")
+    ops.bias_grad(dev(dy), db)
+    assert rel(db, db_e) < 3e-5
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", [(2, 6, 10, 32), (3, 16, 16, 32), (1, 4, 4, 64)])
+def test_convT_s1_tanh_fwd_bwd(ops, case, dtype):
+    B, H, W, cs = case
+    rng = np.random.default_rng(5)
+    x = r32(rng, B, H, W, cs)
+    w = r32(rng, 5, 5, 3, cs, scale=0.05)
+    b = r32(rng, 3, scale=0.1)
+    dpre = r32(rng, B, H, W, 3)
+    pack = ops.conv_pack(dev(w), 3, cs, dtype)
+    y = ops.convT_s1_tanh_fwd(dev(x), pack, dev(b), 3, dtype)
+    assert rel(y, np.tanh(O.conv2d_transpose(x, w, b, 1))) < TOL[dtype]
+    dx_e, dw_e, db_e = O.conv2d_transpose_bwd(x, w, dpre, 1)
+    dx = torch.empty(B, H, W, cs, device="cuda")
+    dw = torch.empty(5, 5, 3, cs, device="cuda")
+    db = torch.empty(3, device="cuda")
+    ops.convT_s1_tanh_bwd(dev(x), dev(dpre), pack, cs, dtype, dx=dx, dw=dw, db=db)
+    assert rel(dx, dx_e) < TOL[dtype]
+    assert rel(dw, dw_e) < 3e-5  # patch wgrad always runs on the exact f32 MFMA
+    assert rel(db, db_e) < 3e-5
+
+
+@pytest.mark.parametrize("pre,post,skip", [(0, 1, False), (1, 0, True), (0, 1, True), (1, 0, False)])
+@pytest.mark.parametrize("shape", [(3, 4, 4, 32), (2, 8, 8, 96), (5, 24576)])
+def test_instnorm_stats_apply_bwd(ops, shape, pre, post, skip):
+    rng = np.random.default_rng(9)
+    a = 0.3
+    x = r32(rng, *shape) * 1.5 + 0.7
+    g = r32(rng, *shape)
+    sk = r32(rng, *shape) if skip else None
+    gamma, beta = 1.3, -0.2
+    xx = O.leaky(x, a) if pre else x
+    y_e, cache = O.instnorm(xx, gamma, beta)
+    out_e = (O.leaky(y_e, a) if post else y_e) + (sk if skip else 0.0)
+    gm, bt = dev(np.array([gamma])), dev(np.array([beta]))
+    stats = ops.instnorm_stats(dev(x), gm, bt, pre, a)
+    B = shape[0]
+    mu_e = xx.reshape(B, -1).mean(1)
+    sd_e = xx.reshape(B, -1).std(1)
+    assert rel(stats[:, 0], mu_e) < 1e-5 and rel(stats[:, 1], sd_e) < 1e-5
+    out = ops.instnorm_apply(dev(x), stats, dev(sk) if skip else None, pre, post, a)
+    assert rel(out, out_e) < 1e-5
+    dy = O.leaky_bwd(y_e, g, a) if post else g
+    dxx_e, dg_e, db_e = O.instnorm_bwd(cache, gamma, dy)
+    dx_e = O.leaky_bwd(x, dxx_e, a) if pre else dxx_e
+    dg, db = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    dx = ops.instnorm_bwd(dev(x), stats, dev(g), dg, db, pre, post, a)
+    assert rel(dx, dx_e) < 2e-5
+    assert abs(dg.item() - dg_e) < 2e-5 * max(1.0, abs(dg_e)) * 10
+    assert abs(db.item() - db_e) < 2e-5 * max(1.0, abs(db_e)) * 10
+
+
+def test_instnorm_constant_sample_is_beta(ops):
+    x = torch.full((2, 4, 4, 32), 3.25, device="cuda")
+    gm, bt = dev(np.array([1.7])), dev(np.array([-0.4]))
+    stats = ops.instnorm_stats(x, gm, bt, 0, 0.3)
+    y = ops.instnorm_apply(x, stats, None, 0, 0, 0.3)
+    assert torch.allclose(y, torch.full_like(y, -0.4), atol=1e-6)
+
+
+@pytest.mark.parametrize("B,K,N", [(5, 133, 24576), (3, 16, 256), (17, 40, 1024)])
+def test_dense_fwd_wgrad(ops, B, K, N):
+    rng = np.random.default_rng(3)
+    x, w, b, dy = r32(rng, B, K), r32(rng, K, N, scale=0.1), r32(rng, N), r32(rng, B, N)
+    y = ops.dense_fwd(dev(x), dev(w), dev(b))
+    assert rel(y, x @ w + b) < 1e-5
+    dw, db = torch.empty(K, N, device="cuda"), torch.empty(N, device="cuda")
+    ops.dense_wgrad(dev(x), dev(dy), dw, db)
+    assert rel(dw, x.T @ dy) < 1e-5 and rel(db, dy.sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("B,K,c", [(5, 24576, 40), (4, 256, 5), (3, 1024, 7)])
+def test_heads_fwd_dgrad_wgrad(ops, B, K, c):
+    rng = np.random.default_rng(4)
+    x = r32(rng, B, K)
+    wpr, wc = r32(rng, K, 1, scale=0.02), r32(rng, K, c, scale=0.02)
+    bpr, bc = r32(rng, 1), r32(rng, c)
+    dz = r32(rng, B, 1 + c)
+    p = ops.heads_fwd(dev(x), dev(wpr), dev(bpr), dev(wc), dev(bc))
+    p_e = np.concatenate([O.sigmoid(x @ wpr + bpr), O.sigmoid(x @ wc + bc)], 1)
+    assert rel(p, p_e) < 1e-5
+    dx = ops.heads_dgrad(dev(dz), dev(wpr), dev(wc))
+    assert rel(dx, dz[:, :1] @ wpr.T + dz[:, 1:] @ wc.T) < 1e-5
+    dwpr, dbpr = torch.empty(K, 1, device="cuda"), torch.empty(1, device="cuda")
+    dwc, dbc = torch.empty(K, c, device="cuda"), torch.empty(c, device="cuda")
+    ops.heads_wgrad(dev(x), dev(dz), dwpr, dbpr, dwc, dbc)
+    assert rel(dwpr, x.T @ dz[:, :1]) < 1e-5 and rel(dwc, x.T @ dz[:, 1:]) < 1e-5
+    assert rel(dbpr, dz[:, 0].sum(0, keepdims=True)) < 1e-5 and rel(dbc, dz[:, 1:].sum(0)) < 1e-5
+
+
+def test_bce_heads_loss(ops):
+    rng = np.random.default_rng(6)
+    B, c = 7, 5
+    p = rng.uniform(0.02, 0.98, (B, 1 + c)).astype(np.float32).astype(np.float64)
+    p[0, 0], p[1, 2] = 0.0, 1.0  # saturated: clipped, zero gradient
+    t_c = O.soft(2.0 * rng.integers(0, 2, (B, c)) - 1.0).astype(np.float32).astype(np.float64)
+    loss = torch.zeros(1, device="cuda")
+    dz = torch.empty(B, 1 + c, device="cuda")
+    ops.bce_heads_loss(dev(p), dev(t_c), O.soft(1.0), 1.0, 2.0, loss, dz, False)
+    exp = O.bce_mean(O.soft(1.0), p[:, :1]) + 2.0 * O.bce_mean(t_c, p[:, 1:])
+    assert abs(loss.item() - exp) < 2e-6 * abs(exp) + 1e-6
+    dp = np.concatenate([O.bce_mean_bwd(O.soft(1.0), p[:, :1]), 2.0 * O.bce_mean_bwd(t_c, p[:, 1:])], 1)
+    assert rel(dz, dp * p * (1 - p)) < 1e-5
+    ops.bce_heads_loss(dev(p), None, O.soft(0.0), 1.0, 0.0, loss, dz, True)
+    exp2 = exp + O.bce_mean(O.soft(0.0), p[:, :1])
+    assert abs(loss.item() - exp2) < 2e-6 * abs(exp2) + 1e-6
+    assert float(dz[:, 1:].abs().max()) == 0.0
+
+
+def test_l1_tanh_loss(ops):
+    rng = np.random.default_rng(7)
+    t = rng.uniform(-1, 1, (3, 8, 8, 3)).astype(np.float32).astype(np.float64)
+    img = np.tanh(r32(rng, 3, 8, 8, 3)).astype(np.float32).astype(np.float64)
+    gin = r32(rng, 3, 8, 8, 3, scale=1e-3)
+    loss = torch.zeros(1, device="cuda")
+    dpre = torch.empty(3, 8, 8, 3, device="cuda")
+    ops.l1_tanh_loss(dev(t), dev(img), dev(gin), dpre, loss, 0.02, False)
+    assert abs(loss.item() - 0.02 * O.l1_mean(t, img)) < 1e-6
+    exp = (gin + 0.02 * O.l1_mean_bwd_b(t, img)) * (1 - img * img)
+    assert rel(dpre, exp) < 1e-5
+
+
+def test_clip_adam(ops):
+    rng = np.random.default_rng(8)
+    n = 1000
+    w0, g = r32(rng, n), r32(rng, n)
+    st = O.AdamState(5e-5, 0.5, 0.9, 1)
+    ws = [w0.copy()]
+    w, m, v = dev(w0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    state = dev(np.array([0.5, 0.9]))
+    for _ in range(3):
+        st.apply(ws, [0], [np.clip(0.5 * g, -0.5, 0.5)])
+        ops.clip_adam_update(w, dev(g), m, v, state, 5e-5, 0.5, 0.9, 1e-8, 0.5, gscale=0.5)
+        ops.adam_advance(state, 0.5, 0.9)
+    assert np.abs(w.cpu().numpy() - ws[0]).max() < 1e-6
+    assert abs(state[0].item() - 0.5 ** 4) < 1e-7
