@@ -78,10 +78,10 @@ int lg_bias_grad(const float* dy, float* db, void* workspace, size_t ws_bytes, l
 
 /* ---- InstanceNormalization(axis=None) + LeakyReLU + skip add  instance.py:105-128, model.py:24,46-50 */
 size_t lg_instnorm_workspace_bytes(int B, long long L);
-/* stats[B][4] = {mu, sigma, a, b} of (pre_leaky ? leaky(x) : x); a = gamma/(sigma+1e-3), b = beta - a*mu */
+/* stats[B][4] = {mu, sigma, a, beta} of (pre_leaky ? leaky(x) : x); a = gamma/(sigma+1e-3) */
 int lg_instnorm_leaky_stats(const float* x, float* stats, const float* gamma, const float* beta, void* workspace,
                             size_t ws_bytes, int B, long long L, int pre_leaky, float alpha, void* stream);
-/* y = [post_leaky](a*[pre_leaky](x) + b) [+ skip] */
+/* y = [post_leaky](a*([pre_leaky](x) - mu) + beta) [+ skip] */
 int lg_instnorm_leaky_apply(const float* x, const float* stats, const float* skip, float* y, int B, long long L,
                             int pre_leaky, int post_leaky, float alpha, void* stream);
 /* g = dL/dy (before skip) -> dx ; dgamma/dbeta (device scalars, may be null) */

@@ -4,8 +4,8 @@
 // a_n = gamma/(sigma_n+eps), b_n = beta - a_n*mu_n; LeakyReLU(0.3) (model.py:24,50,100,130) and the
 // decoder's skip add (model.py:46-47) are fused into the same elementwise pass.
 //   stats : two-level reduction, block-local mean / M2 (registers) merged with Chan's formula in fp64
-//           in a fixed order -> deterministic, no atomics.   stats[n] = {mu, sigma, a, b}
-//   apply : y = [leaky]( a*[leaky](x) + b ) [+ skip]
+//           in a fixed order -> deterministic, no atomics.   stats[n] = {mu, sigma, a, beta}
+//   apply : y = [leaky]( a*([leaky](x) - mu) + beta ) [+ skip]
 //   bwd   : dx = a*(dz - mean(dz) - c*mean(dz*c)/((sigma+eps)*sigma)), c = x-mu ; dgamma, dbeta.
 // All HBM-bound: 16-B vector loads, one pass over x for the moments (values kept in registers).
 #include "lg_common.h"
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void stats_final_kernel(const float* __restrict
     const double sigma = sqrt(m2 / cnt);
     const double a = (double)gamma[0] / (sigma + (double)LG_IN_EPS);
     float* o = stats + (long long)n * 4;
-    o[0] = (float)mean; o[1] = (float)sigma; o[2] = (float)a; o[3] = (float)((double)beta[0] - a * mean);
+    o[0] = (float)mean; o[1] = (float)sigma; o[2] = (float)a; o[3] = beta[0];
   }
 }
 
@@ -94,13 +94,13 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ x,
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
     const int n = (int)(i / L4);
-    const float a = stats[n * 4 + 2], b = stats[n * 4 + 3];
+    const float mu = stats[n * 4], a = stats[n * 4 + 2], b = stats[n * 4 + 3];
     f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float t = v[k];
       if (pre_leaky) t = lg_leaky(t, alpha);
-      t = a * t + b;
+      t = a * (t - mu) + b;  // (x-mu)/(sigma+eps)*gamma + beta, as instance.py:116-127 (no cancellation)
       if (post_leaky) t = lg_leaky(t, alpha);
       v[k] = t;
     }
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restric
         float xx = xv[k];
         if (pre_leaky) xx = lg_leaky(xx, alpha);
         float dz = gv[k];
-        if (post_leaky) dz = (a * xx + b > 0.f) ? dz : alpha * dz;
+        if (post_leaky) dz = (a * (xx - mu) + b > 0.f) ? dz : alpha * dz;
         s1 += dz;
         s2 += dz * (xx - mu);
       }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
       float xx = xv[k];
       if (pre_leaky) xx = lg_leaky(xx, alpha);
       float dz = gv[k];
-      if (post_leaky) dz = (a * xx + b > 0.f) ? dz : alpha * dz;
+      if (post_leaky) dz = (a * (xx - mu) + b > 0.f) ? dz : alpha * dz;
       float d = a * (dz - m1 - (xx - mu) * m2);
       if (pre_leaky) d = (xv[k] > 0.f) ? d : alpha * d;
       o[k] = d;

@@ -1,0 +1,245 @@
+"""EagerTrainer — host-side mirror of /root/reference/eager_trainer.py on the HIP kernels.
+
+The hot path is `train_step_from_inputs` = the arithmetic of eager_trainer.py:133-168 (the two
+GradientTapes replaced by a static backward plan), called by `_train_step` (eager_trainer.py:115-169)
+after it has drawn the two batches, the noise and the augmented image.  Data parallelism (new,
+BASELINE.json north star): one process per GPU, the three gradient sets are contiguous ranges of one
+flat buffer and are all-reduced (RCCL) on a side stream while the next tape's backward runs.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .dist import GradSync
+from .model import Adjuster, Discriminator, Generator, ParamStore
+from .utils import save_image, soft
+
+ADAM_EPS = 1e-8
+
+
+def train_weight_range(args, model: str, batch_no: int):
+    """eager_trainer.py:104-113 + part_groups :48-52 as (lo, hi) weight-index ranges."""
+    groups = {"G": [(0, 4), (4, 8), (8, 22)], "D": [(0, 12), (12, 16), (16, 20)], "A": [(0, 4)]}[model]
+    n_all = {"G": 22, "D": 20, "A": 4}[model]
+    if args.use_partition and batch_no % (args.partition_interval + 1) == 0:
+        return groups[(batch_no // (args.partition_interval + 1)) % len(groups)]
+    return (0, n_all)
+
+
+class EagerTrainer:
+    def __init__(self, args, generator: Generator, discriminator: Discriminator, adjuster: Adjuster, dataset):
+        self.args = args
+        print(" - Initializing Trainer(Executor)...")
+        self.dataset = dataset
+        self.adjuster = adjuster
+        self.discriminator = discriminator
+        self.generator = generator
+        self.models = [self.discriminator, self.generator, self.adjuster]
+        self.device = generator.device
+        if getattr(args, "use_gp", False):  # eager_trainer.py:141-143
+            raise NotImplementedError("GP didn't implemented on eager mode")
+        self.store = ParamStore(generator, discriminator, adjuster)
+        # tf.compat.v1.train.AdamOptimizer x3 (eager_trainer.py:28-30): {beta1_power, beta2_power} per optimizer
+        self.opt_cfg = {"G": (args.lr, args.beta_1, args.beta_2), "D": (args.lr, args.beta_1, args.beta_2),
+                        "A": (args.lr, 0.9, 0.999)}
+        self.opt_state = {m: torch.tensor([b1, b2], dtype=torch.float32, device=self.device)
+                          for m, (_, b1, b2) in self.opt_cfg.items()}
+        self.losses = {k: torch.zeros(1, dtype=torch.float32, device=self.device) for k in ("gen", "disc", "adj")}
+        self.sync = GradSync(self.device)
+        self.global_epoch = 1
+        self._init_dir()
+        self._init_test_data()
+
+    # ------------------------------------------------------------------ hot path
+    def train_step_from_inputs(self, batch_no: int, inp: Dict[str, torch.Tensor]):
+        """inp: real_image_1, real_cond_1, real_image_2, real_cond_2, noise, new_image (device fp32, NHWC).
+        Returns (fake_image, adj_image|None, gen_loss, disc_loss, adj_loss|None) — losses are 1-element
+        device tensors (no host sync on the hot path)."""
+        a = self.args
+        G, D, A = self.generator, self.discriminator, self.adjuster
+        img1, c1, img2, c2 = inp["real_image_1"], inp["real_cond_1"], inp["real_image_2"], inp["real_cond_2"]
+        noise, new_image = inp["noise"], inp["new_image"]
+        B = img1.shape[0]
+        c = a.cond_dim
+
+        # ---- forward: fake = G(noise, c2); D on the [new_image ; fake] batch (eager_trainer.py:134-137)
+        ctx_g: dict = {}
+        d_in = torch.empty((2 * B,) + tuple(img1.shape[1:]), dtype=torch.float32, device=self.device)
+        d_in[:B].copy_(new_image)
+        fake = G([noise, c2], ctx_g, out=d_in[B:])
+        ctx_d: dict = {}
+        p = D.forward_packed(d_in, ctx_d)  # [2B, 1+c]: rows [0,B) real, [B,2B) fake
+
+        # ---- disc tape (eager_trainer.py:139,145): 2*BCE(c1,real_c) + BCE(.98,real_pr) + BCE(.02,fake_pr)
+        dz = torch.empty(2 * B, 1 + c, dtype=torch.float32, device=self.device)
+        ops.bce_heads_loss(p[:B], c1, soft(1.0), 1.0, 2.0, self.losses["disc"], dz[:B], False)
+        ops.bce_heads_loss(p[B:], None, soft(0.0), 1.0, 0.0, self.losses["disc"], dz[B:], True)
+        D.backward(ctx_d, dz, need_wgrad=True, need_input_grad=False)
+        self.sync.launch("D", self.store, *self.store.model_range("D"))
+
+        # ---- gen tape (eager_trainer.py:140,149): BCE(.98,fake_pr) + BCE(c2,fake_c) + l1*mean|img2-fake|
+        dz_g = torch.empty(B, 1 + c, dtype=torch.float32, device=self.device)
+        ops.bce_heads_loss(p[B:], c2, soft(1.0), 1.0, 1.0, self.losses["gen"], dz_g, False)
+        g_img = D.backward(ctx_d, dz_g, need_wgrad=False, need_input_grad=True, rows=slice(B, 2 * B))
+        dpre = torch.empty_like(g_img)
+        ops.l1_tanh_loss(img2, fake, g_img, dpre, self.losses["gen"], a.l1_lambda, True)
+        G.backward(ctx_g, dpre)
+        self.sync.launch("G", self.store, *self.store.model_range("G"))
+
+        # ---- adjuster branch (eager_trainer.py:152-164)
+        adj_image = None
+        run_adj = bool(a.train_adj and batch_no > 10)
+        if run_adj:
+            adj_in_cond = (torch.cat([c2, c1], 0) + 1.0) * 0.5
+            adj_t_cond = torch.cat([c2, c1], 0)
+            adj_in_img = torch.cat([img1, fake], 0)
+            adj_t_img = torch.cat([img2, img1], 0)
+            ctx_a: dict = {}
+            adj_image = A([adj_in_img, adj_in_cond], ctx_a)
+            ctx_d2: dict = {}
+            p_a = D.forward_packed(adj_image, ctx_d2)
+            dz_a = torch.empty(2 * B, 1 + c, dtype=torch.float32, device=self.device)
+            ops.bce_heads_loss(p_a, adj_t_cond, soft(1.0), 1.0, 1.0, self.losses["adj"], dz_a, False)
+            g_adj = D.backward(ctx_d2, dz_a, need_wgrad=False, need_input_grad=True)
+            dpre_a = torch.empty_like(g_adj)
+            ops.l1_tanh_loss(adj_t_img, adj_image, g_adj, dpre_a, self.losses["adj"], a.l1_lambda, True)
+            A.backward_own(ctx_a, dpre_a)
+            self.sync.launch("A", self.store, *self.store.model_range("A"))
+
+        # ---- optimizer applies, order A, D, G (eager_trainer.py:164-168); D-grads clipped after all-reduce
+        self.sync.wait_all()
+        gscale = 1.0 / self.sync.world_size
+        for m in (("A",) if run_adj else ()) + ("D", "G"):
+            lo, hi = train_weight_range(a, m, batch_no)
+            s, e = self.store.model_range(m, lo, hi)
+            lr, b1, b2 = self.opt_cfg[m]
+            clip = a.clip_range if (m == "D" and a.use_clip) else 0.0
+            st = self.store
+            ops.clip_adam_update(st.flat[s:e], st.grad[s:e], st.m[s:e], st.v[s:e], self.opt_state[m], lr, b1, b2,
+                                 ADAM_EPS, clip, gscale)
+            ops.adam_advance(self.opt_state[m], b1, b2)
+        self.store.bump()
+        return (fake, adj_image, self.losses["gen"], self.losses["disc"], self.losses["adj"] if run_adj else None)
+
+    # ------------------------------------------------------------------ eager_trainer.py:115-169
+    def _train_step(self, batch_no, iterator):
+        try:
+            real_image_1, real_cond_1 = iterator.get_next()
+            real_image_2, real_cond_2 = iterator.get_next()
+        except StopIteration:  # tf.errors.OutOfRangeError
+            return None,
+        if not real_cond_1.shape[0] == real_cond_2.shape[0] == self.args.batch_size:
+            return False,
+        noise = torch.randn(self.args.batch_size, self.args.noise_dim, device=self.device)
+        new_image = augment(real_image_1)
+        inp = dict(real_image_1=real_image_1, real_cond_1=real_cond_1, real_image_2=real_image_2,
+                   real_cond_2=real_cond_2, noise=noise, new_image=new_image)
+        fake, adj, lg, ld, la = self.train_step_from_inputs(batch_no, inp)
+        return True, fake, adj, lg, ld, la
+
+    # ------------------------------------------------------------------ eager_trainer.py:180-229
+    def train(self):
+        a = self.args
+        for e in range(self.global_epoch, a.epoch + 1):
+            print("Experiment:", a.exp_name, "Epoch:", e, "Starting...")
+            self.global_epoch = e
+            iterator = self.dataset.get_new_iterator()
+            start_time = time.time()
+            seen = 0
+            for b in range(1, self.dataset.batches + 1):
+                result = self._train_step(b, iterator)
+                if result[0] is None:
+                    break
+                elif not result[0]:
+                    continue
+                seen += a.batch_size * 2
+                if b % a.freq_gen == 0:
+                    save_image(result[1], os.path.join(a.result_dir, "train", "gen", "%d-%d.jpg" % (e, b)))
+                    if result[2] is not None:
+                        save_image(result[2], os.path.join(a.result_dir, "train", "adj", "%d-%d.jpg" % (e, b)))
+                    lg, ld = float(result[3]), float(result[4])
+                    la = float(result[5]) if result[5] is not None else float("nan")
+                    print(f"  [{seen}] LossG {lg:.4f} LossD {ld:.4f} LossA {la:.4f}")
+                if b % a.freq_test == 0:
+                    self.predict(self.test_noise, self.test_cond, self.test_image,
+                                 os.path.join(a.result_dir, "test", "gen", "%d-%d.jpg" % (e, b)),
+                                 os.path.join(a.result_dir, "test", "disc", "%d-%d.json" % (e, b)),
+                                 os.path.join(a.result_dir, "test", "adj", "%d-%d.jpg" % (e, b)))
+            torch.cuda.synchronize()
+            print("Time usage:", time.time() - start_time, "s")
+
+    # ------------------------------------------------------------------ eager_trainer.py:265-298
+    def predict(self, noise, cond, image, gen_image_save_path=None, json_save_path=None, adj_image_save_path=None):
+        start_time = time.time()
+        gen_image = self.generator([noise, cond])
+        torch.cuda.synchronize()
+        print("Generate Time", time.time() - start_time, "s")
+        if gen_image_save_path is not None:
+            save_image(gen_image, gen_image_save_path)
+        save = dict()
+        save["real_cond"] = cond
+        save["real_pr"], save["real_c"] = self.discriminator(image)
+        save["fake_pr"], save["fake_c"] = self.discriminator(gen_image)
+        mse = lambda t, p: float(((t - p) ** 2).mean(dim=-1).mean(dim=0))
+        save["real_pr_mse"] = mse(soft(1.0), save["real_pr"])
+        save["real_c_mse"] = mse(cond, save["real_c"])
+        save["fake_pr_mse"] = mse(soft(0.0), save["fake_pr"])
+        save["fake_c_mse"] = mse(cond, save["fake_c"])
+        for x in ["real_cond", "real_pr", "real_c", "fake_c", "fake_pr"]:
+            save[x] = torch.round(save[x] * 100).to(torch.int64).cpu().tolist()
+        if json_save_path is not None:
+            with open(json_save_path, "w") as f:
+                json.dump(save, f)
+        adj_fake_image, adj_real_image = None, None
+        if self.args.train_adj:
+            adj_real_image = self.adjuster([image, cond])
+            adj_fake_image = self.adjuster([gen_image, cond])
+            if adj_image_save_path is not None:
+                save_image(torch.cat([adj_real_image, adj_fake_image], 0), adj_image_save_path)
+        return gen_image, save, adj_real_image, adj_fake_image
+
+    # ------------------------------------------------------------------ shell (own format; TF checkpoints are out of scope)
+    def _init_dir(self):
+        rd = getattr(self.args, "result_dir", None)
+        if not rd or getattr(self.args, "no_io", False):
+            return
+        for item in [".", "train/gen", "train/adj", "test/adj", "test/gen", "test/disc", "checkpoint", "log", "sample",
+                     "evaluate/gen", "evaluate/adj", "evaluate/disc", "model"]:
+            os.makedirs(os.path.join(rd, item), exist_ok=True)
+
+    def _init_test_data(self):
+        self.test_noise = self.test_cond = self.test_image = None
+        if self.dataset is None:
+            return
+        it = self.dataset.get_new_iterator()
+        self.test_image, self.test_cond = it.get_next()
+        self.test_noise = torch.randn(self.test_cond.shape[0], self.args.noise_dim, device=self.device)
+
+    def export_model_checkpoint(self):
+        path = os.path.join(self.args.result_dir, "model", "model.pt")
+        torch.save({"names": {m: self.store.names(m) for m in "GDA"}, "flat": self.store.flat.cpu()}, path)
+        return path
+
+    def plot(self):
+        raise NotImplementedError("plot (keras plot_model / pydot) is UI tooling outside the hot path (SURVEY.md §2 row 5)")
+
+
+def augment(image: torch.Tensor) -> torch.Tensor:
+    """Input side of the step (eager_trainer.py:127-131).  The TF image ops are RNG- and kernel-specific, so
+    parity treats `new_image` as an INPUT; this is a plain torch stand-in with the same
+    structure (flip, brightness +-0.02, contrast [0.75,1.003], + 0.1*N(0,0.2)); hue is not applied."""
+    B = image.shape[0]
+    dev = image.device
+    flip = torch.rand(B, device=dev) < 0.5
+    x = torch.where(flip.view(B, 1, 1, 1), image.flip(2), image)
+    x = x + (torch.rand(B, 1, 1, 1, device=dev) * 0.04 - 0.02)
+    cf = 0.75 + torch.rand(B, 1, 1, 1, device=dev) * (1.003 - 0.75)
+    mean = x.mean(dim=(1, 2), keepdim=True)
+    x = (x - mean) * cf + mean
+    return (x + 0.1 * torch.randn_like(x) * 0.2).contiguous()

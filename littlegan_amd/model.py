@@ -1,0 +1,439 @@
+"""Host-side mirror of /root/reference/model.py on the HIP kernels (no autograd, no fallback).
+
+Same constructors and call signatures as the reference (main.py:20-24):
+    Decoder(args), Encoder(args), Generator(args, decoder), Discriminator(args, encoder),
+    Adjuster(args, discriminator, generator)
+    G([noise, cond]) -> image[B,H,W,3];  D(image) -> (pr[B,1], c[B,cond_dim]);  A([image, cond]) -> image
+and the same `.weights` ordering (eager_trainer.py:48-63 indexes into it): Generator 22,
+Discriminator 20, Adjuster 38 (own = [16:20]).  Tensors are NHWC fp32 torch CUDA tensors.
+
+Every forward can record a context (`ctx`) holding exactly what the hand-written backward needs:
+the layer inputs, the raw (pre-norm) conv outputs and the per-sample norm statistics.  The
+backward methods compute the gradient sets of eager_trainer.py:145,149,163 and nothing else.
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from ._lib import DT_BF16, DT_F32
+
+
+def _dtype_of(args) -> int:
+    name = getattr(args, "mfma_dtype", "f32")
+    if name not in ("f32", "bf16"):
+        raise ValueError(f"mfma_dtype must be 'f32' or 'bf16', got {name!r}")
+    return DT_BF16 if name == "bf16" else DT_F32
+
+
+def _device_of(args):
+    return torch.device(getattr(args, "device", "cuda"))
+
+
+def _glorot(shape, gen, device):
+    """TF default kernel initializer (glorot_uniform) of tf.compat.v1.layers.{Dense,Conv2D,Conv2DTranspose}."""
+    if len(shape) == 2:
+        fan_in, fan_out = shape
+    else:
+        rf = math.prod(shape[:-2])
+        fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return ((torch.rand(shape, generator=gen, dtype=torch.float32) * 2.0 - 1.0) * lim).to(device)
+
+
+class _Module:
+    """Minimal stand-in for keras.Model: ordered named weights + optional flat-store gradients."""
+
+    def __init__(self, args):
+        self.args = args
+        self.device = _device_of(args)
+        self.dtype = _dtype_of(args)
+        self._names: List[str] = []
+        self._w: Dict[str, torch.Tensor] = {}
+        self._g: Dict[str, torch.Tensor] = {}  # gradient views, installed by ParamStore.adopt
+        seed = getattr(args, "seed", 0)
+        self._gen = torch.Generator().manual_seed(int(seed) * 1000 + zlib.crc32(type(self).__name__.encode()) % 1000)
+
+    def _add(self, name, shape, kind):
+        if kind == "kernel":
+            t = _glorot(tuple(shape), self._gen, self.device)
+        elif kind == "ones":
+            t = torch.ones(shape, dtype=torch.float32, device=self.device)
+        else:
+            t = torch.zeros(shape, dtype=torch.float32, device=self.device)
+        self._names.append(name)
+        self._w[name] = t
+
+    @property
+    def weights(self) -> List[torch.Tensor]:
+        return [self._w[n] for n in self._names]
+
+    def own_items(self):
+        return [(n, self._w[n]) for n in self._names]
+
+    def grad(self, name) -> Optional[torch.Tensor]:
+        return self._g.get(name)
+
+
+class _ConvStack(_Module):
+    """Four 5x5 stride-2 layers + InstanceNormalization, shared machinery of Encoder / Decoder."""
+
+    def __init__(self, args, chans):
+        super().__init__(args)
+        self.chans = chans  # [(cb, cs)] per layer
+        self._packs: List[Optional[torch.Tensor]] = [None] * 4
+        self._pack_version = -1
+        self.version = 0  # bumped by whoever updates the weights
+        for i, (cb, cs) in enumerate(chans, 1):
+            self._add(f"conv{i}.kernel", (5, 5, cb, cs), "kernel")
+            self._add(f"conv{i}.bias", (self._bias_dim(cb, cs),), "zeros")
+            self._add(f"norm{i}.gamma", (1,), "ones")
+            self._add(f"norm{i}.beta", (1,), "zeros")
+
+    def packs(self):
+        if self._pack_version != self.version:
+            for i, (cb, cs) in enumerate(self.chans):
+                self._packs[i] = ops.conv_pack(self._w[f"conv{i + 1}.kernel"], cb, cs, self.dtype, out=self._packs[i])
+            self._pack_version = self.version
+        return self._packs
+
+
+class Encoder(_ConvStack):
+    """model.py:6-27.  conv_i: Conv2D(conv_filter[4-i], 5, 2, 'same') -> InstanceNorm -> leaky -> dropout(identity)."""
+
+    def __init__(self, args):
+        cf = args.conv_filter
+        chans, cin = [], args.image_channel
+        for i in range(1, 5):
+            chans.append((cin, cf[4 - i]))
+            cin = cf[4 - i]
+        super().__init__(args, chans)
+
+    @staticmethod
+    def _bias_dim(cb, cs):
+        return cs
+
+    def __call__(self, inputs, ctx: Optional[dict] = None):
+        x = inputs
+        a = self.args.leaky_alpha
+        packs = self.packs()
+        outs = []
+        saved = []
+        for i, (cb, cs) in enumerate(self.chans, 1):
+            z = ops.conv2d_s2_fwd(x, packs[i - 1], self._w[f"conv{i}.bias"], cs, self.dtype)
+            st = ops.instnorm_stats(z, self._w[f"norm{i}.gamma"], self._w[f"norm{i}.beta"], 0, a)
+            h = ops.instnorm_apply(z, st, None, 0, 1, a)
+            saved.append((x, z, st))
+            outs.append(h)
+            x = h
+        if ctx is not None:
+            ctx["enc"] = saved
+        return outs
+
+    def backward(self, ctx, g_last, need_wgrad: bool, need_input_grad: bool, rows: Optional[slice] = None):
+        """g_last: gradient w.r.t. the LAST returned map (the only one any tape of the step uses).
+        rows: restrict to a batch slice of the recorded context (the fake half of a [real;fake] batch)."""
+        a = self.args.leaky_alpha
+        packs = self.packs()
+        g_h = g_last
+        for i in range(4, 0, -1):
+            cb, cs = self.chans[i - 1]
+            x, z, st = ctx["enc"][i - 1]
+            if rows is not None:
+                x, z, st = x[rows], z[rows], st[rows]
+            dgm = self._g[f"norm{i}.gamma"] if need_wgrad else None
+            dbt = self._g[f"norm{i}.beta"] if need_wgrad else None
+            dz = ops.instnorm_bwd(z, st, g_h, dgm, dbt, 0, 1, a)
+            if need_wgrad:
+                ops.conv2d_s2_wgrad(x, dz, self._g[f"conv{i}.kernel"], False, self.dtype)
+                ops.bias_grad(dz, self._g[f"conv{i}.bias"])
+            g_h = ops.conv2d_s2_dgrad(dz, packs[i - 1], cb, self.dtype) if (i > 1 or need_input_grad) else None
+        return g_h
+
+
+class Decoder(_ConvStack):
+    """model.py:30-51.  conv_i: Conv2DTranspose(conv_filter[i], 5, (2,2), 'same') -> InstanceNorm -> leaky,
+    with `x += add[i-1]` in front of every level whose skip is not None."""
+
+    def __init__(self, args):
+        cf = args.conv_filter
+        super().__init__(args, [(cf[i], cf[i - 1]) for i in range(1, 5)])  # (cb=out, cs=in)
+
+    @staticmethod
+    def _bias_dim(cb, cs):
+        return cb
+
+    def __call__(self, inputs, ctx: Optional[dict] = None):
+        x, add = inputs
+        a = self.args.leaky_alpha
+        packs = self.packs()
+        saved = []
+        if add[0] is not None:
+            x = x + add[0]  # tiny (init_dim^2 x conv_filter[0]); later skips are fused into the norm-apply pass
+        for i, (cb, cs) in enumerate(self.chans, 1):
+            z = ops.convT_s2_fwd(x, packs[i - 1], self._w[f"conv{i}.bias"], cb, self.dtype)
+            st = ops.instnorm_stats(z, self._w[f"norm{i}.gamma"], self._w[f"norm{i}.beta"], 0, a)
+            skip = add[i] if i < 4 else None
+            h = ops.instnorm_apply(z, st, skip, 0, 1, a)
+            saved.append((x, z, st))
+            x = h
+        if ctx is not None:
+            ctx["dec"] = saved
+        return x
+
+    def backward(self, ctx, g_h, need_wgrad: bool):
+        """Returns the gradient w.r.t. the decoder input x (skip tensors receive the same gradient as the
+        level input they were added to; no tape of the step asks for it)."""
+        a = self.args.leaky_alpha
+        packs = self.packs()
+        for i in range(4, 0, -1):
+            cb, cs = self.chans[i - 1]
+            x, z, st = ctx["dec"][i - 1]
+            dgm = self._g[f"norm{i}.gamma"] if need_wgrad else None
+            dbt = self._g[f"norm{i}.beta"] if need_wgrad else None
+            dz = ops.instnorm_bwd(z, st, g_h, dgm, dbt, 0, 1, a)
+            if need_wgrad:
+                ops.convT_s2_wgrad(x, dz, self._g[f"conv{i}.kernel"], False, self.dtype)
+                ops.bias_grad(dz, self._g[f"conv{i}.bias"])
+            g_h = ops.convT_s2_dgrad(dz, packs[i - 1], cs, self.dtype)
+        return g_h
+
+
+class _FinalConv(_Module):
+    """Conv2DTranspose(image_channel, 5, strides 1, 'same', activation tanh)  model.py:86-87."""
+
+    def __init__(self, args):
+        super().__init__(args)
+        self.cb, self.cs = args.image_channel, args.conv_filter[4]
+        self._add("kernel", (5, 5, self.cb, self.cs), "kernel")
+        self._add("bias", (self.cb,), "zeros")
+        self._pack = None
+        self._pack_version = -1
+        self.version = 0
+
+    def pack(self):
+        if self._pack_version != self.version:
+            self._pack = ops.conv_pack(self._w["kernel"], self.cb, self.cs, self.dtype, out=self._pack)
+            self._pack_version = self.version
+        return self._pack
+
+    def __call__(self, x, out=None):
+        return ops.convT_s1_tanh_fwd(x, self.pack(), self._w["bias"], self.cb, self.dtype, out=out)
+
+    def backward(self, x, dpre, need_wgrad: bool):
+        B, H, W, _ = dpre.shape
+        dx = torch.empty(B, H, W, self.cs, dtype=torch.float32, device=dpre.device)
+        ops.convT_s1_tanh_bwd(x if need_wgrad else None, dpre, self.pack(), self.cs, self.dtype, dx=dx,
+                              dw=self._g["kernel"] if need_wgrad else None,
+                              db=self._g["bias"] if need_wgrad else None)
+        return dx
+
+
+class _DenseNorm(_Module):
+    """Dense(init_dim^2 * conv_filter[0]) -> leaky -> InstanceNormalization   (model.py:83-84,98-102 and
+    :120-121,128-131; the norm sees a 4-D tensor in G and a 2-D one in A — same per-sample moments)."""
+
+    def __init__(self, args, in_dim):
+        super().__init__(args)
+        self.in_dim = in_dim
+        self.out_dim = args.init_dim ** 2 * args.conv_filter[0]
+        self._add("dense.kernel", (in_dim, self.out_dim), "kernel")
+        self._add("dense.bias", (self.out_dim,), "zeros")
+        self._add("norm.gamma", (1,), "ones")
+        self._add("norm.beta", (1,), "zeros")
+
+    def __call__(self, x, ctx: Optional[dict] = None):
+        a = self.args.leaky_alpha
+        u = ops.dense_fwd(x, self._w["dense.kernel"], self._w["dense.bias"])
+        st = ops.instnorm_stats(u, self._w["norm.gamma"], self._w["norm.beta"], 1, a)
+        w = ops.instnorm_apply(u, st, None, 1, 0, a)
+        if ctx is not None:
+            ctx["dn"] = (x, u, st)
+        return w.view(-1, self.args.init_dim, self.args.init_dim, self.args.conv_filter[0])
+
+    def backward(self, ctx, g):
+        x, u, st = ctx["dn"]
+        a = self.args.leaky_alpha
+        du = ops.instnorm_bwd(u, st, g.reshape(u.shape), self._g["norm.gamma"], self._g["norm.beta"], 1, 0, a)
+        ops.dense_wgrad(x, du, self._g["dense.kernel"], self._g["dense.bias"])
+
+
+class Generator(_Module):
+    """model.py:76-105."""
+
+    def __init__(self, args, decoder: Decoder):
+        super().__init__(args)
+        self._dn = _DenseNorm(args, args.noise_dim + args.cond_dim)
+        self.decoder = decoder
+        self.conv = _FinalConv(args)
+
+    # reference attribute names (model.py:83-86)
+    @property
+    def dense(self):
+        return self._dn
+
+    @property
+    def norm(self):
+        return self._dn
+
+    def parts(self):
+        return [("gen.", self._dn), ("dec.", self.decoder), ("gen.conv.", self.conv)]
+
+    @property
+    def weights(self):
+        return self._dn.weights + self.decoder.weights + self.conv.weights
+
+    def __call__(self, inputs, ctx: Optional[dict] = None, out=None):
+        noise, cond = inputs
+        x0 = torch.cat([noise, cond], dim=-1).contiguous()
+        w4 = self._dn(x0, ctx)
+        xdec = self.decoder([w4, [None] * 4], ctx)
+        img = self.conv(xdec, out=out)
+        if ctx is not None:
+            ctx["xdec"], ctx["img"] = xdec, img
+        return img
+
+    def backward(self, ctx, dpre):
+        """dpre = dL/d(pre-tanh image).  Writes all 22 weight gradients."""
+        g = self.conv.backward(ctx["xdec"], dpre, need_wgrad=True)
+        g = self.decoder.backward(ctx, g, need_wgrad=True)
+        self._dn.backward(ctx, g)
+
+
+class Discriminator(_Module):
+    """model.py:54-73.  Returns (output_pr [B,1], output_cond [B,cond_dim]) as views of one [B,1+c] buffer."""
+
+    def __init__(self, args, encoder: Encoder):
+        super().__init__(args)
+        self.encoder = encoder
+        k = args.init_dim ** 2 * args.conv_filter[0]
+        self._add("dense_pr.kernel", (k, 1), "kernel")
+        self._add("dense_pr.bias", (1,), "zeros")
+        self._add("dense_cond.kernel", (k, args.cond_dim), "kernel")
+        self._add("dense_cond.bias", (args.cond_dim,), "zeros")
+
+    def parts(self):
+        return [("enc.", self.encoder), ("disc.", self)]
+
+    @property
+    def weights(self):
+        return self.encoder.weights + [self._w[n] for n in self._names]
+
+    def forward_packed(self, image, ctx: Optional[dict] = None):
+        outs = self.encoder(image, ctx)
+        x = outs[3].view(image.shape[0], -1)
+        p = ops.heads_fwd(x, self._w["dense_pr.kernel"], self._w["dense_pr.bias"], self._w["dense_cond.kernel"],
+                          self._w["dense_cond.bias"])
+        if ctx is not None:
+            ctx["heads_x"] = x
+        return p
+
+    def __call__(self, inputs, ctx: Optional[dict] = None):
+        p = self.forward_packed(inputs, ctx)
+        return p[:, :1], p[:, 1:]
+
+    def backward(self, ctx, dz, need_wgrad: bool, need_input_grad: bool, rows: Optional[slice] = None):
+        """dz [B,1+c] = dL/d(logits).  need_wgrad: the disc tape (all 20 gradients); otherwise only the data
+        path down to the image (gen / adj tapes)."""
+        x = ctx["heads_x"] if rows is None else ctx["heads_x"][rows]
+        if need_wgrad:
+            ops.heads_wgrad(x, dz, self._g["dense_pr.kernel"], self._g["dense_pr.bias"], self._g["dense_cond.kernel"],
+                            self._g["dense_cond.bias"])
+        dx = ops.heads_dgrad(dz, self._w["dense_pr.kernel"], self._w["dense_cond.kernel"])
+        i, f = self.args.init_dim, self.args.conv_filter[0]
+        return self.encoder.backward(ctx, dx.view(-1, i, i, f), need_wgrad, need_input_grad, rows)
+
+
+class Adjuster(_Module):
+    """model.py:108-136: encoder shared with D, decoder and final conv shared with G; own = dense, norm."""
+
+    def __init__(self, args, discriminator: Discriminator, generator: Generator):
+        super().__init__(args)
+        self.encoder = discriminator.encoder
+        self._dn = _DenseNorm(args, args.cond_dim)
+        self.decoder = generator.decoder
+        self.conv = generator.conv
+
+    @property
+    def dense(self):
+        return self._dn
+
+    @property
+    def norm(self):
+        return self._dn
+
+    def parts(self):
+        return [("adj.", self._dn)]
+
+    @property
+    def weights(self):
+        return self.encoder.weights + self._dn.weights + self.decoder.weights + self.conv.weights
+
+    def __call__(self, inputs, ctx: Optional[dict] = None):
+        image, cond = inputs
+        enc = self.encoder(image)  # no context: no tape of the step differentiates through it
+        c4 = self._dn(cond.contiguous(), ctx)
+        x = self.decoder([c4, enc[::-1]], ctx)
+        img = self.conv(x)
+        if ctx is not None:
+            ctx["xdec"], ctx["img"] = x, img
+        return img
+
+    def backward_own(self, ctx, dpre):
+        """Gradient w.r.t. Adjuster.weights[16:20] only (eager_trainer.py:51,62,163)."""
+        g = self.conv.backward(None, dpre, need_wgrad=False)
+        g = self.decoder.backward(ctx, g, need_wgrad=False)
+        self._dn.backward(ctx, g)
+
+
+# ----------------------------------------------------------------------------------------------
+class ParamStore:
+    """Re-homes every weight of (G, D, A-own) into ONE flat fp32 buffer, in the order
+    [Generator.weights (22) | Discriminator.weights (20) | Adjuster.weights[16:20] (4)], each weight
+    16-byte aligned, with same-layout gradient and Adam-slot buffers.  The three optimizers, the
+    partition groups (eager_trainer.py:48-52) and the data-parallel all-reduce buckets then are
+    contiguous ranges of it."""
+
+    def __init__(self, generator: Generator, discriminator: Discriminator, adjuster: Adjuster):
+        self.models = {"G": generator, "D": discriminator, "A": adjuster}
+        entries = []  # (model, name, module, local name, numel, shape)
+        for m, mod in self.models.items():
+            for prefix, part in mod.parts():
+                for name, t in part.own_items():
+                    entries.append((m, prefix + name, part, name, t.numel(), tuple(t.shape)))
+        off = 0
+        self.index = []
+        for m, full, part, name, n, shp in entries:
+            self.index.append((m, full, part, name, off, n, shp))
+            off += (n + 3) // 4 * 4
+        dev = generator.device
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.ranges = {}  # model -> [(start, end_padded)] per weight index
+        for m, full, part, name, o, n, shp in self.index:
+            view = self.flat[o:o + n].view(shp)
+            view.copy_(part._w[name])
+            part._w[name] = view
+            part._g[name] = self.grad[o:o + n].view(shp)
+            self.ranges.setdefault(m, []).append((o, o + (n + 3) // 4 * 4))
+        self._stacks = [discriminator.encoder, generator.decoder, generator.conv]
+
+    def model_range(self, m, idx_lo=None, idx_hi=None):
+        r = self.ranges[m]
+        lo = 0 if idx_lo is None else idx_lo
+        hi = len(r) if idx_hi is None else idx_hi
+        return r[lo][0], r[hi - 1][1]
+
+    def names(self, m):
+        return [full for mm, full, *_ in self.index if mm == m]
+
+    def bump(self):
+        """Weights changed: conv packs must be rebuilt before the next forward."""
+        for s in self._stacks:
+            s.version += 1
