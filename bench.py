@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py — LittleGAN training-step throughput on MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W [--workload c3|c2] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path (eager_trainer.py:133-168 of the reference: G fwd, D fwd on
+[real;fake], disc tape, gen tape, Adjuster branch, D-clip, three Adam applies) on one synthetic batch
+already resident in HBM.  Metric (BASELINE.json): 128x128 images/sec, images = batch_size per step
+(one batch of fakes generated per step; the reference's Progbar counts 2*batch_size consumed samples).
+Workloads:  c3 (default; the config the metric is quoted on): 128^2, B=256/GPU, bf16 MFMA, G+D+Adj
+            c2: 128^2, B=64/GPU, exact-f32 MFMA, G+D only (train_adj off)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md:41-43
+# algorithmic conv/convT/dense FLOPs per image of the per-device batch at 128^2, c=40
+GFLOP_PER_IMAGE = {"c3": 27.03, "c2": 13.25}
+
+
+def make_args(workload, device):
+    c3 = workload == "c3"
+    return SimpleNamespace(
+        batch_size=256 if c3 else 64, image_channel=3, noise_dim=93, init_dim=8, conv_filter=[384, 256, 128, 64, 32],
+        kernel_size=5, leaky_alpha=0.3, dropout_rate=0.5, l1_lambda=0.02, lr=5e-5, beta_1=0.5, beta_2=0.9,
+        use_gp=False, use_clip=True, clip_range=0.5, use_partition=True, partition_interval=4,
+        train_adj=c3, cond_dim=40, mfma_dtype="bf16" if c3 else "f32", device=device, seed=0, no_io=True)
+
+
+def synthetic_inputs(args, device, rank):
+    """images U(-1,1), conds soft(+-1), noise N(0,1); seed 1234 + rank."""
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    B, H = args.batch_size, args.init_dim * 16
+    img = lambda: (torch.rand(B, H, H, 3, generator=g) * 2 - 1).to(device)
+    cond = lambda: (0.96 * (2.0 * torch.randint(0, 2, (B, args.cond_dim), generator=g).float() - 1.0) + 0.02).to(device)
+    return dict(real_image_1=img(), real_cond_1=cond(), real_image_2=img(), real_cond_2=cond(),
+                noise=torch.randn(B, args.noise_dim, generator=g).to(device), new_image=img())
+
+
+def cpu_baseline(workload):
+    """The oracle's torch-CPU fp32 restatement of the SAME step on a bounded sample (B=8), host cores of this box.
+    Label: CPU restatement, not TensorFlow (TF 1.15 cannot run in this pipeline)."""
+    from oracle import np_oracle as O
+    from oracle import torch_oracle as T
+    Bc = 8
+    cfg = O.Cfg(batch_size=Bc, cond_dim=40, train_adj=(workload == "c3"))
+    W = O.init_weights(cfg, 0)
+    tr = T.Trainer(cfg, W, dtype=torch.float32)
+    inp = {k: torch.tensor(v, dtype=torch.float32) for k, v in O.make_inputs(cfg, Bc, 1234).items()}
+    tr.step(11, inp)  # warm-up (allocations, oneDNN primitives)
+    n, t0 = 0, time.perf_counter()
+    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 20):
+        tr.step(12 + n, inp)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(Bc / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"torch-CPU fp32 restatement (oracle/torch_oracle.py) of the same {workload} step at 128x128, "
+                      f"batch {Bc}, {n} timed steps, {dt:.2f} s/step, nproc={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["c3", "c2"], default="c3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from littlegan_amd import ops
+    from littlegan_amd.eager_trainer import EagerTrainer
+    from littlegan_amd.model import Adjuster, Decoder, Discriminator, Encoder, Generator
+    args = make_args(a.workload, str(device))
+    decoder, encoder = Decoder(args), Encoder(args)
+    gen = Generator(args, decoder)
+    disc = Discriminator(args, encoder)
+    adj = Adjuster(args, disc, gen)
+    tr = EagerTrainer(args, gen, disc, adj, None)
+    if world > 1:  # identical initial weights on every rank
+        import torch.distributed as dist
+        dist.broadcast(tr.store.flat, src=0)
+        tr.store.bump()
+    inp = synthetic_inputs(args, device, rank)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    b0 = 11  # batch_no > 10 so the Adjuster branch runs (eager_trainer.py:152); every 5th step is a partition step
+    for i in range(a.warmup):
+        tr.train_step_from_inputs(b0 + i, inp)
+    barrier()
+    ops.Profile.start()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        tr.train_step_from_inputs(b0 + a.warmup + i, inp)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ops.Profile.stop()
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = {k: float(v.item()) for k, v in tr.losses.items()}
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        gb = args.batch_size * world
+        value = gb / (dt / a.steps)
+        dt_name = args.mfma_dtype
+        # dominant kernel = the conv contraction class with the largest measured time
+        tag, (n, fl, sec) = max(prof.items(), key=lambda kv: kv[1][2])
+        ach = fl / sec / 1e12
+        conv_sec = sum(v[2] for v in prof.values())
+        conv_fl = sum(v[1] for v in prof.values())
+        out = {
+            "metric": "128x128 CelebA-shaped images/sec (G+D+Adj step)" if a.workload == "c3" else "128x128 CelebA-shaped images/sec (G+D step)",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": dt_name, "data": "synthetic",
+            "config": {"workload": ("C3: 128x128x3 synthetic CelebA, batch 256/GPU, bf16 MFMA conv/transposed-conv + Adjuster branch"
+                                    if a.workload == "c3" else "C2: 128x128x3 synthetic CelebA, batch 64/GPU, exact-f32 MFMA, G+D step only"),
+                       "global_batch": gb, "per_gpu_batch": args.batch_size, "image": 128, "cond_dim": 40,
+                       "parallelism": f"dp{world}", "consumed_samples_per_step": 2 * gb},
+            "roofline": {"bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": PEAK[dt_name], "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK[dt_name], 4), "traffic": None,
+                         "launches": n, "avg_launch_ms": round(sec / n * 1e3, 4),
+                         "all_conv_kernels": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 2),
+                                                  "ms_per_step": round(v[2] / a.steps * 1e3, 3)} for k, v in prof.items()},
+                         "conv_share_of_step": round(conv_sec / dt, 3),
+                         "conv_tflops_overall": round(conv_fl / conv_sec / 1e12, 2),
+                         "step_algorithmic_tflops": round(GFLOP_PER_IMAGE[a.workload] * args.batch_size / ms, 2)},
+            "losses_last_step": losses,
+            "parity": "checked against the in-repo fp64 restatement (tests/); parity to TensorFlow 1.15 is UNPINNED",
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.workload)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,7 +78,9 @@ int lg_bias_grad(const float* dy, float* db, void* workspace, size_t ws_bytes, l
 
 /* ---- InstanceNormalization(axis=None) + LeakyReLU + skip add  instance.py:105-128, model.py:24,46-50 */
 size_t lg_instnorm_workspace_bytes(int B, long long L);
-/* stats[B][4] = {mu, sigma, a, beta} of (pre_leaky ? leaky(x) : x); a = gamma/(sigma+1e-3) */
+/* stats[B][8] = {mu_hi, sigma, a, beta, mu_lo, 0,0,0} of (pre_leaky ? leaky(x) : x); a = gamma/(sigma+1e-3);
+ * mu = mu_hi + mu_lo (float-float: the mean is subtracted from every element, its rounding error is coherent) */
+int lg_instnorm_stats_stride(void);
 int lg_instnorm_leaky_stats(const float* x, float* stats, const float* gamma, const float* beta, void* workspace,
                             size_t ws_bytes, int B, long long L, int pre_leaky, float alpha, void* stream);
 /* y = [post_leaky](a*([pre_leaky](x) - mu) + beta) [+ skip] */

@@ -34,6 +34,7 @@ SIGNATURES = {
     "lg_bias_grad_workspace_bytes": (Z, [L, I]),
     "lg_bias_grad": (I, [P, P, P, Z, L, I, I, P]),
     "lg_instnorm_workspace_bytes": (Z, [I, L]),
+    "lg_instnorm_stats_stride": (I, []),
     "lg_instnorm_leaky_stats": (I, [P, P, P, P, P, Z, I, L, I, F, P]),
     "lg_instnorm_leaky_apply": (I, [P, P, P, P, I, L, I, I, F, P]),
     "lg_instnorm_leaky_bwd": (I, [P, P, P, P, P, P, P, Z, I, L, I, I, F, I, P]),

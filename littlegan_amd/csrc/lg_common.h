@@ -84,4 +84,26 @@ __device__ __forceinline__ void lg_block_sum(float (&v)[NV], float* smem /* >= N
   }
 }
 
+// block-wide sum of NV doubles; result valid in thread 0.  smem >= NV*16 doubles.
+template <int NV>
+__device__ __forceinline__ void lg_block_sum_d(double (&v)[NV], double* smem) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = lg_wave_sum_d(v[i]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) smem[i * 16 + wid] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      double s = 0.0;
+      for (int w = 0; w < nw; ++w) s += smem[i * 16 + w];
+      v[i] = s;
+    }
+  }
+}
+
 static inline int lg_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,30 +1,36 @@
 // InstanceNormalization(axis=None, eps=1e-3) of /root/reference/instance.py:105-128 as used at
 // model.py:16,41,84,121: per-SAMPLE moments over all of (H,W,C), scalar gamma/beta, eps added to the
-// std.  Because gamma/beta are scalars the whole op is a per-sample affine  y = a_n*x + b_n  with
-// a_n = gamma/(sigma_n+eps), b_n = beta - a_n*mu_n; LeakyReLU(0.3) (model.py:24,50,100,130) and the
-// decoder's skip add (model.py:46-47) are fused into the same elementwise pass.
-//   stats : two-level reduction, block-local mean / M2 (registers) merged with Chan's formula in fp64
-//           in a fixed order -> deterministic, no atomics.   stats[n] = {mu, sigma, a, beta}
-//   apply : y = [leaky]( a*([leaky](x) - mu) + beta ) [+ skip]
-//   bwd   : dx = a*(dz - mean(dz) - c*mean(dz*c)/((sigma+eps)*sigma)), c = x-mu ; dgamma, dbeta.
-// All HBM-bound: 16-B vector loads, one pass over x for the moments (values kept in registers).
+// std.  Because gamma/beta are scalars the whole op is a per-sample affine y = a_n*(x - mu_n) + beta with
+// a_n = gamma/(sigma_n+eps); LeakyReLU(0.3) (model.py:24,50,100,130) and the decoder's skip add
+// (model.py:46-47) are fused into the same elementwise pass.
+//   stats : two-level reduction, block-local mean / M2 merged with Chan's formula, everything accumulated
+//           in fp64 in a fixed order -> deterministic, no atomics.
+//           stats[n][8] = {mu_hi, sigma, a, beta, mu_lo, 0, 0, 0}   (mu = mu_hi + mu_lo, float-float)
+//   apply : y = [leaky]( a*(([leaky](x) - mu_hi) - mu_lo) + beta ) [+ skip]
+//   bwd   : dx = a*(dz - m1 - c*m2'), c = x-mu, m1 = mean(dz), m2' = mean(dz*c)/((sigma+eps)*sigma);
+//           dgamma = sum dz*c/(sigma+eps), dbeta = sum dz.
+// Why fp64 sums and float-float means: mu, m1 and m2' are subtracted from EVERY element of a sample, so their
+// rounding error is coherent; the later reductions of the step (bias / weight gradients = sums over up to
+// 10^6 pixels of quantities whose mean was removed here) amplify a coherent 1e-7 error to 1e-3.
+// All kernels are HBM-bound: 16-B vector loads, one pass over x for the moments (values kept in registers).
 #include "lg_common.h"
 
 #define LG_IN_EPS 1e-3f
+#define LG_NSTAT 8
 
 namespace {
 
 constexpr int CHUNK = 4096;  // elements per block in the reduction passes (256 threads x 4 float4)
 
-// partial[n][chunk] = {count, mean, M2}
-__global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+// partial[n][chunk] = {count, mean, M2} (doubles)
+__global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restrict__ x, double* __restrict__ partial,
                                                             long long L, int nchunk, int pre_leaky, float alpha) {
   const int n = blockIdx.y, ch = blockIdx.x;
   const long long base = (long long)n * L + (long long)ch * CHUNK;
   const long long lim = L - (long long)ch * CHUNK;  // valid elements in this chunk
-  __shared__ float sred[32];
+  __shared__ double sred[32];
   f32x4 v[4];
-  float s = 0.f;
+  double s = 0.0;
   int cnt = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -36,54 +42,56 @@ __global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[q][k] = lg_leaky(v[q][k], alpha);
       }
-      s += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+      s += ((double)v[q][0] + (double)v[q][1]) + ((double)v[q][2] + (double)v[q][3]);
       cnt += 4;
     }
   }
-  float red[2] = {s, (float)cnt};
-  lg_block_sum<2>(red, sred);
-  __shared__ float s_mean;
+  double red[2] = {s, (double)cnt};
+  lg_block_sum_d<2>(red, sred);
+  __shared__ double s_mean;
   if (threadIdx.x == 0) s_mean = red[0] / red[1];
   __syncthreads();
-  const float mean = s_mean;
-  float m2 = 0.f;
+  const double mean = s_mean;
+  double m2 = 0.0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int e = (q * 256 + threadIdx.x) * 4;
     if (e < lim) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { const float d = v[q][k] - mean; m2 += d * d; }
+      for (int k = 0; k < 4; ++k) { const double d = (double)v[q][k] - mean; m2 += d * d; }
     }
   }
-  float red2[1] = {m2};
-  lg_block_sum<1>(red2, sred);
+  double red2[1] = {m2};
+  lg_block_sum_d<1>(red2, sred);
   if (threadIdx.x == 0) {
-    float* o = partial + ((long long)n * nchunk + ch) * 3;
+    double* o = partial + ((long long)n * nchunk + ch) * 3;
     o[0] = red[1]; o[1] = mean; o[2] = red2[0];
   }
 }
 
 // one wave per sample: Chan merge of the chunk partials in fp64
-__global__ __launch_bounds__(64) void stats_final_kernel(const float* __restrict__ partial, float* __restrict__ stats,
+__global__ __launch_bounds__(64) void stats_final_kernel(const double* __restrict__ partial, float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          int nchunk) {
   const int n = blockIdx.x, lane = threadIdx.x;
-  const float* p = partial + (long long)n * nchunk * 3;
+  const double* p = partial + (long long)n * nchunk * 3;
   double cnt = 0.0, sum = 0.0;
-  for (int i = lane; i < nchunk; i += 64) { cnt += (double)p[i * 3]; sum += (double)p[i * 3] * (double)p[i * 3 + 1]; }
+  for (int i = lane; i < nchunk; i += 64) { cnt += p[i * 3]; sum += p[i * 3] * p[i * 3 + 1]; }
   cnt = lg_wave_sum_d(cnt); sum = lg_wave_sum_d(sum);
   const double mean = sum / cnt;
   double m2 = 0.0;
   for (int i = lane; i < nchunk; i += 64) {
-    const double d = (double)p[i * 3 + 1] - mean;
-    m2 += (double)p[i * 3 + 2] + (double)p[i * 3] * d * d;
+    const double d = p[i * 3 + 1] - mean;
+    m2 += p[i * 3 + 2] + p[i * 3] * d * d;
   }
   m2 = lg_wave_sum_d(m2);
   if (lane == 0) {
     const double sigma = sqrt(m2 / cnt);
     const double a = (double)gamma[0] / (sigma + (double)LG_IN_EPS);
-    float* o = stats + (long long)n * 4;
-    o[0] = (float)mean; o[1] = (float)sigma; o[2] = (float)a; o[3] = beta[0];
+    float* o = stats + (long long)n * LG_NSTAT;
+    const float mu_hi = (float)mean;
+    o[0] = mu_hi; o[1] = (float)sigma; o[2] = (float)a; o[3] = beta[0];
+    o[4] = (float)(mean - (double)mu_hi); o[5] = 0.f; o[6] = 0.f; o[7] = 0.f;
   }
 }
 
@@ -94,13 +102,14 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ x,
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
     const int n = (int)(i / L4);
-    const float mu = stats[n * 4], a = stats[n * 4 + 2], b = stats[n * 4 + 3];
+    const float* sp = stats + (long long)n * LG_NSTAT;
+    const float mu = sp[0], a = sp[2], b = sp[3], mul = sp[4];
     f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float t = v[k];
       if (pre_leaky) t = lg_leaky(t, alpha);
-      t = a * (t - mu) + b;  // (x-mu)/(sigma+eps)*gamma + beta, as instance.py:116-127 (no cancellation)
+      t = a * ((t - mu) - mul) + b;  // (x-mu)/(sigma+eps)*gamma + beta, as instance.py:116-127 (no cancellation)
       if (post_leaky) t = lg_leaky(t, alpha);
       v[k] = t;
     }
@@ -109,17 +118,19 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ x,
   }
 }
 
-// partial[n][chunk] = {sum dz, sum dz*c}
+// partial[n][chunk] = {sum dz, sum dz*c} (doubles)
 __global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                          const float* __restrict__ stats, float* __restrict__ partial,
+                                                          const float* __restrict__ stats, double* __restrict__ partial,
                                                           long long L, int nchunk, int pre_leaky, int post_leaky,
                                                           float alpha) {
   const int n = blockIdx.y, ch = blockIdx.x;
   const long long base = (long long)n * L + (long long)ch * CHUNK;
   const long long lim = L - (long long)ch * CHUNK;
-  const float mu = stats[n * 4], a = stats[n * 4 + 2], b = stats[n * 4 + 3];
-  __shared__ float sred[32];
-  float s1 = 0.f, s2 = 0.f;
+  const float* sp = stats + (long long)n * LG_NSTAT;
+  const float mu = sp[0], a = sp[2], b = sp[3], mul = sp[4];
+  const double mud = (double)mu + (double)mul;
+  __shared__ double sred[32];
+  double s1 = 0.0, s2 = 0.0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int e = (q * 256 + threadIdx.x) * 4;
@@ -131,33 +142,35 @@ __global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restric
         float xx = xv[k];
         if (pre_leaky) xx = lg_leaky(xx, alpha);
         float dz = gv[k];
-        if (post_leaky) dz = (a * (xx - mu) + b > 0.f) ? dz : alpha * dz;
-        s1 += dz;
-        s2 += dz * (xx - mu);
+        if (post_leaky) dz = (a * ((xx - mu) - mul) + b > 0.f) ? dz : alpha * dz;
+        s1 += (double)dz;
+        s2 += (double)dz * ((double)xx - mud);
       }
     }
   }
-  float red[2] = {s1, s2};
-  lg_block_sum<2>(red, sred);
+  double red[2] = {s1, s2};
+  lg_block_sum_d<2>(red, sred);
   if (threadIdx.x == 0) {
-    float* o = partial + ((long long)n * nchunk + ch) * 2;
+    double* o = partial + ((long long)n * nchunk + ch) * 2;
     o[0] = red[0]; o[1] = red[1];
   }
 }
 
-// bstats[n] = {m1, m2/(s*sigma)} ; dgamma/dbeta reduced over samples by block 0 in a second launch
-__global__ __launch_bounds__(64) void bwd_final_kernel(const float* __restrict__ partial, const float* __restrict__ stats,
+// bstats[n][4] = {m1_hi, m2'_hi, m1_lo, m2'_lo} ; gsum[n] = per-sample dgamma / dbeta contributions
+__global__ __launch_bounds__(64) void bwd_final_kernel(const double* __restrict__ partial, const float* __restrict__ stats,
                                                        float* __restrict__ bstats, double* __restrict__ gsum,
                                                        long long L, int nchunk) {
   const int n = blockIdx.x, lane = threadIdx.x;
-  const float* p = partial + (long long)n * nchunk * 2;
+  const double* p = partial + (long long)n * nchunk * 2;
   double s1 = 0.0, s2 = 0.0;
-  for (int i = lane; i < nchunk; i += 64) { s1 += (double)p[i * 2]; s2 += (double)p[i * 2 + 1]; }
+  for (int i = lane; i < nchunk; i += 64) { s1 += p[i * 2]; s2 += p[i * 2 + 1]; }
   s1 = lg_wave_sum_d(s1); s2 = lg_wave_sum_d(s2);
   if (lane == 0) {
-    const double sigma = (double)stats[n * 4 + 1], s = sigma + (double)LG_IN_EPS;
-    bstats[n * 2] = (float)(s1 / (double)L);
-    bstats[n * 2 + 1] = (float)(s2 / (double)L / (s * sigma));
+    const double sigma = (double)stats[(long long)n * LG_NSTAT + 1], s = sigma + (double)LG_IN_EPS;
+    const double m1 = s1 / (double)L, m2 = s2 / (double)L / (s * sigma);
+    const float m1h = (float)m1, m2h = (float)m2;
+    bstats[n * 4] = m1h; bstats[n * 4 + 1] = m2h;
+    bstats[n * 4 + 2] = (float)(m1 - (double)m1h); bstats[n * 4 + 3] = (float)(m2 - (double)m2h);
     gsum[n * 2] = s2 / s;  // dgamma contribution
     gsum[n * 2 + 1] = s1;  // dbeta contribution
   }
@@ -187,8 +200,9 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
     const int n = (int)(i / L4);
-    const float mu = stats[n * 4], a = stats[n * 4 + 2], b = stats[n * 4 + 3];
-    const float m1 = bstats[n * 2], m2 = bstats[n * 2 + 1];
+    const float* sp = stats + (long long)n * LG_NSTAT;
+    const float mu = sp[0], a = sp[2], b = sp[3], mul = sp[4];
+    const float m1 = bstats[n * 4], m2 = bstats[n * 4 + 1], m1l = bstats[n * 4 + 2], m2l = bstats[n * 4 + 3];
     const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
     const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
     f32x4 o;
@@ -196,9 +210,10 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
     for (int k = 0; k < 4; ++k) {
       float xx = xv[k];
       if (pre_leaky) xx = lg_leaky(xx, alpha);
+      const float c = (xx - mu) - mul;
       float dz = gv[k];
-      if (post_leaky) dz = (a * (xx - mu) + b > 0.f) ? dz : alpha * dz;
-      float d = a * (dz - m1 - (xx - mu) * m2);
+      if (post_leaky) dz = (a * c + b > 0.f) ? dz : alpha * dz;
+      float d = a * ((((dz - m1) - m1l) - c * m2) - c * m2l);
       if (pre_leaky) d = (xv[k] > 0.f) ? d : alpha * d;
       o[k] = d;
     }
@@ -211,18 +226,19 @@ inline int ew_blocks(long long total4) {
   long long b = (total4 + 255) / 256;
   return (int)(b < 8192 ? b : 8192);
 }
+inline size_t part_bytes(int B, long long L) { return ((size_t)B * nchunks(L) * 3 * sizeof(double) + 255) / 256 * 256; }
+inline size_t bst_bytes(int B) { return ((size_t)B * 4 * sizeof(float) + 255) / 256 * 256; }
 
 }  // namespace
 
+extern "C" int lg_instnorm_stats_stride(void) { return LG_NSTAT; }
+
 extern "C" size_t lg_instnorm_workspace_bytes(int B, long long L) {
-  // partials (3 floats per chunk) + bstats (2 floats) + gsum (2 doubles) per sample, 256-B aligned pieces
-  const size_t part = ((size_t)B * nchunks(L) * 3 * sizeof(float) + 255) / 256 * 256;
-  const size_t bst = ((size_t)B * 2 * sizeof(float) + 255) / 256 * 256;
   const size_t gs = ((size_t)B * 2 * sizeof(double) + 255) / 256 * 256;
-  return part + bst + gs;
+  return part_bytes(B, L) + bst_bytes(B) + gs;
 }
 
-// stats[B][4] = {mu, sigma, a, b} of (pre_leaky ? leaky(x) : x), x = [B][L]
+// stats[B][8] = {mu_hi, sigma, a, beta, mu_lo, 0,0,0} of (pre_leaky ? leaky(x) : x), x = [B][L]
 extern "C" int lg_instnorm_leaky_stats(const float* x, float* stats, const float* gamma, const float* beta,
                                        void* workspace, size_t ws_bytes, int B, long long L, int pre_leaky,
                                        float alpha, void* stream) {
@@ -231,14 +247,14 @@ extern "C" int lg_instnorm_leaky_stats(const float* x, float* stats, const float
   LG_CHECK_ARG(ws_bytes >= lg_instnorm_workspace_bytes(B, L), "lg_instnorm_leaky_stats: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int nc = nchunks(L);
-  hipLaunchKernelGGL(stats_partial_kernel, dim3(nc, B), dim3(256), 0, st, x, (float*)workspace, L, nc, pre_leaky, alpha);
+  hipLaunchKernelGGL(stats_partial_kernel, dim3(nc, B), dim3(256), 0, st, x, (double*)workspace, L, nc, pre_leaky, alpha);
   LG_CHECK_LAUNCH("lg_instnorm_leaky_stats(partial)");
-  hipLaunchKernelGGL(stats_final_kernel, dim3(B), dim3(64), 0, st, (const float*)workspace, stats, gamma, beta, nc);
+  hipLaunchKernelGGL(stats_final_kernel, dim3(B), dim3(64), 0, st, (const double*)workspace, stats, gamma, beta, nc);
   LG_CHECK_LAUNCH("lg_instnorm_leaky_stats(final)");
   return LG_OK;
 }
 
-// y = [post_leaky] (a_n * [pre_leaky](x) + b_n) [+ skip]
+// y = [post_leaky] (a_n * ([pre_leaky](x) - mu_n) + beta) [+ skip]
 extern "C" int lg_instnorm_leaky_apply(const float* x, const float* stats, const float* skip, float* y, int B,
                                        long long L, int pre_leaky, int post_leaky, float alpha, void* stream) {
   LG_CHECK_ARG(x && stats && y, "lg_instnorm_leaky_apply: null pointer");
@@ -260,15 +276,13 @@ extern "C" int lg_instnorm_leaky_bwd(const float* x, const float* stats, const f
   hipStream_t st = (hipStream_t)stream;
   const int nc = nchunks(L);
   char* ws = (char*)workspace;
-  float* partial = (float*)ws;
-  const size_t part = ((size_t)B * nc * 3 * sizeof(float) + 255) / 256 * 256;
-  float* bstats = (float*)(ws + part);
-  const size_t bst = ((size_t)B * 2 * sizeof(float) + 255) / 256 * 256;
-  double* gsum = (double*)(ws + part + bst);
+  double* partial = (double*)ws;
+  float* bstats = (float*)(ws + part_bytes(B, L));
+  double* gsum = (double*)(ws + part_bytes(B, L) + bst_bytes(B));
   hipLaunchKernelGGL(bwd_partial_kernel, dim3(nc, B), dim3(256), 0, st, x, g, stats, partial, L, nc, pre_leaky,
                      post_leaky, alpha);
   LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd(partial)");
-  hipLaunchKernelGGL(bwd_final_kernel, dim3(B), dim3(64), 0, st, (const float*)partial, stats, bstats, gsum, L, nc);
+  hipLaunchKernelGGL(bwd_final_kernel, dim3(B), dim3(64), 0, st, (const double*)partial, stats, bstats, gsum, L, nc);
   LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd(final)");
   if (dgamma && dbeta) {
     hipLaunchKernelGGL(bwd_affine_grad_kernel, dim3(1), dim3(256), 0, st, (const double*)gsum, dgamma, dbeta, B,

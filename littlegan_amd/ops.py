@@ -12,6 +12,45 @@ from . import _lib
 from ._lib import DT_BF16, DT_F32, check
 
 _WS = {}
+NSTAT = 8  # floats per sample in the instance-norm statistics record (lg_instnorm_stats_stride)
+
+
+class Profile:
+    """Optional per-launch HIP-event timing of the conv contractions (bench.py's live roofline leg).
+    Events are recorded on torch's current stream = the stream the kernels are launched on."""
+    enabled = False
+    records = []  # (tag, algorithmic flops, start event, end event)
+
+    @classmethod
+    def start(cls):
+        cls.records = []
+        cls.enabled = True
+
+    @classmethod
+    def stop(cls):
+        """-> {tag: (launches, total flops, total seconds)} ; call after a device synchronize"""
+        cls.enabled = False
+        out = {}
+        for tag, fl, e0, e1 in cls.records:
+            n, f, t = out.get(tag, (0, 0.0, 0.0))
+            out[tag] = (n + 1, f + fl, t + e0.elapsed_time(e1) * 1e-3)
+        cls.records = []
+        return out
+
+
+def _pb():
+    if not Profile.enabled:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _pe(e0, tag, flops):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        Profile.records.append((tag, float(flops), e0, e1))
 
 
 def _stream():
@@ -64,8 +103,10 @@ def conv2d_s2_fwd(x, pack, bias, cs, dtype, out=None):
     _chk(out, (B, H // 2, W // 2, cs), "out")
     if bias is not None:
         _chk(bias, (cs,), "bias")
+    e0 = _pb()
     check(_lib.load().lg_conv2d_s2_fwd(_p(x), _p(pack), _p(bias), _p(out), B, H // 2, W // 2, cb, cs, dtype, _stream()),
           "lg_conv2d_s2_fwd")
+    _pe(e0, "conv_igemm_patch" if cb == 3 else "conv_igemm_down", 50.0 * B * (H // 2) * (W // 2) * cb * cs)
     return out
 
 
@@ -75,8 +116,10 @@ def conv2d_s2_dgrad(dy, pack, cb, dtype, out=None):
     if out is None:
         out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.float32, device=dy.device)
     _chk(out, (B, 2 * Hs, 2 * Ws, cb), "out")
+    e0 = _pb()
     check(_lib.load().lg_conv2d_s2_dgrad(_p(dy), _p(pack), _p(out), B, Hs, Ws, cb, cs, dtype, _stream()),
           "lg_conv2d_s2_dgrad")
+    _pe(e0, "conv_igemm_up_n3" if cb == 3 else "conv_igemm_up", 50.0 * B * Hs * Ws * cb * cs)
     return out
 
 
@@ -90,8 +133,10 @@ def _wgrad(fn_name, big, small, dw, accumulate, dtype, swap):
     nbytes = int(lib.lg_wgrad_workspace_bytes(B, Hs, Ws, cb, cs, dtype))
     ws = workspace(nbytes, big.device, "wgrad")
     a, b = (small, big) if swap else (big, small)
+    e0 = _pb()
     check(getattr(lib, fn_name)(_p(a), _p(b), _p(dw), _p(ws), ws.numel(), B, Hs, Ws, cb, cs, int(accumulate), dtype,
                                 _stream()), fn_name)
+    _pe(e0, "wgrad_patch" if cb == 3 else "wgrad_igemm", 50.0 * B * Hs * Ws * cb * cs)
     return dw
 
 
@@ -108,8 +153,10 @@ def convT_s2_fwd(x, pack, bias, cb, dtype, out=None):
     _chk(out, (B, 2 * Hs, 2 * Ws, cb), "out")
     if bias is not None:
         _chk(bias, (cb,), "bias")
+    e0 = _pb()
     check(_lib.load().lg_convT_s2_fwd(_p(x), _p(pack), _p(bias), _p(out), B, Hs, Ws, cb, cs, dtype, _stream()),
           "lg_convT_s2_fwd")
+    _pe(e0, "conv_igemm_up", 50.0 * B * Hs * Ws * cb * cs)
     return out
 
 
@@ -119,8 +166,10 @@ def convT_s2_dgrad(dy, pack, cs, dtype, out=None):
     if out is None:
         out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.float32, device=dy.device)
     _chk(out, (B, H // 2, W // 2, cs), "out")
+    e0 = _pb()
     check(_lib.load().lg_convT_s2_dgrad(_p(dy), _p(pack), _p(out), B, H // 2, W // 2, cb, cs, dtype, _stream()),
           "lg_convT_s2_dgrad")
+    _pe(e0, "conv_igemm_down", 50.0 * B * (H // 2) * (W // 2) * cb * cs)
     return out
 
 
@@ -136,8 +185,10 @@ def convT_s1_tanh_fwd(x, pack, bias, cb, dtype, out=None):
         out = torch.empty(B, H, W, cb, dtype=torch.float32, device=x.device)
     _chk(out, (B, H, W, cb), "out")
     _chk(bias, (cb,), "bias")
+    e0 = _pb()
     check(_lib.load().lg_convT_s1_tanh_fwd(_p(x), _p(pack), _p(bias), _p(out), B, H, W, cb, cs, dtype, _stream()),
           "lg_convT_s1_tanh_fwd")
+    _pe(e0, "conv_igemm_s1t_n3", 50.0 * B * H * W * cb * cs)
     return out
 
 
@@ -177,8 +228,8 @@ def instnorm_stats(x, gamma, beta, pre_leaky, alpha, stats=None):
     Ln = x.numel() // B
     _chk(x, name="x")
     if stats is None:
-        stats = torch.empty(B, 4, dtype=torch.float32, device=x.device)
-    _chk(stats, (B, 4), "stats")
+        stats = torch.empty(B, NSTAT, dtype=torch.float32, device=x.device)
+    _chk(stats, (B, NSTAT), "stats")
     lib = _lib.load()
     ws = workspace(int(lib.lg_instnorm_workspace_bytes(B, Ln)), x.device, "small")
     check(lib.lg_instnorm_leaky_stats(_p(x), _p(stats), _p(gamma), _p(beta), _p(ws), ws.numel(), B, Ln, int(pre_leaky),
@@ -190,7 +241,7 @@ def instnorm_apply(x, stats, skip, pre_leaky, post_leaky, alpha, out=None):
     B = x.shape[0]
     Ln = x.numel() // B
     _chk(x, name="x")
-    _chk(stats, (B, 4), "stats")
+    _chk(stats, (B, NSTAT), "stats")
     if skip is not None:
         _chk(skip, name="skip")
         if skip.numel() != x.numel():
@@ -210,7 +261,7 @@ def instnorm_bwd(x, stats, g, dgamma, dbeta, pre_leaky, post_leaky, alpha, accum
     _chk(g, name="g")
     if g.numel() != x.numel():
         raise ValueError("instnorm_bwd: g has a different size")
-    _chk(stats, (B, 4), "stats")
+    _chk(stats, (B, NSTAT), "stats")
     if out is None:
         out = torch.empty_like(x)
     _chk(out, x.shape, "out")

