@@ -1,0 +1,143 @@
+"""CPU tests of the host logic of the product path that needs no GPU:
+  * ParamStore layout (22 / 20 / 4 weights, reference order, contiguous optimizer + partition ranges),
+  * the partition schedule mirror (eager_trainer.py:104-113),
+  * the data-parallel gradient exchange (littlegan_amd.dist.GradSync) on a world_size-2 gloo group:
+    mean of the per-rank gradients == gradient of the single-process step on the concatenated batch.
+Gradients on CPU come from the torch oracle (the HIP kernels cannot run here); only the exchange is under test."""
+import os
+import socket
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import np_oracle as O
+from oracle import torch_oracle as T
+
+CFG = dict(init_dim=2, conv_filter=(32, 32, 32, 32, 32), cond_dim=3, noise_dim=5, batch_size=2)
+
+
+def _args(cfg):
+    d = {k: getattr(cfg, k) for k in ("batch_size", "image_channel", "noise_dim", "init_dim", "conv_filter", "kernel_size",
+                                      "leaky_alpha", "l1_lambda", "lr", "beta_1", "beta_2", "use_clip", "clip_range",
+                                      "use_partition", "partition_interval", "train_adj", "cond_dim")}
+    return SimpleNamespace(**d, mfma_dtype="f32", device="cpu", seed=0, use_gp=False, no_io=True, dropout_rate=0.5)
+
+
+def _store(cfg):
+    from littlegan_amd.model import Adjuster, Decoder, Discriminator, Encoder, Generator, ParamStore
+    a = _args(cfg)
+    dec, enc = Decoder(a), Encoder(a)
+    g = Generator(a, dec)
+    d = Discriminator(a, enc)
+    adj = Adjuster(a, d, g)
+    return ParamStore(g, d, adj), g, d, adj
+
+
+def test_param_store_layout_matches_reference_order():
+    cfg = O.Cfg(**CFG)
+    store, g, d, adj = _store(cfg)
+    shapes = O.weight_shapes(cfg)
+    for m, model_w in (("G", g.weights), ("D", d.weights), ("A", adj.weights[16:20])):
+        assert [tuple(w.shape) for w in model_w] == [s for _, s in shapes[m]]
+        assert store.names(m) == [n for n, _ in shapes[m]]
+        prev_end = store.ranges[m][0][0]
+        for (s, e), w in zip(store.ranges[m], model_w):
+            assert s == prev_end and s % 4 == 0 and e - s >= w.numel()  # contiguous, 16-byte aligned
+            assert w.data_ptr() == store.flat[s:].data_ptr()  # weights ARE views of the flat buffer
+            prev_end = e
+    assert len(adj.weights) == 38 and len(g.weights) == 22 and len(d.weights) == 20
+    # Adjuster shares encoder / decoder / final conv storage with D / G (model.py:119-123)
+    assert adj.weights[0].data_ptr() == d.weights[0].data_ptr()
+    assert adj.weights[20].data_ptr() == g.weights[4].data_ptr()
+    assert adj.weights[36].data_ptr() == g.weights[20].data_ptr()
+    # G, D, A ranges are disjoint and ordered
+    assert store.model_range("G")[1] <= store.model_range("D")[0] and store.model_range("D")[1] <= store.model_range("A")[0]
+
+
+def test_partition_schedule_mirror():
+    from littlegan_amd.eager_trainer import train_weight_range
+    cfg = O.Cfg(**CFG)
+    a = _args(cfg)
+    for b in range(1, 31):
+        for m in "GDA":
+            lo, hi = train_weight_range(a, m, b)
+            assert list(range(lo, hi)) == O.train_weight_indices(cfg, m, b)
+    a.use_partition = False
+    assert train_weight_range(a, "G", 5) == (0, 22)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from littlegan_amd.dist import GradSync
+        cfg = O.Cfg(**CFG)
+        W = O.init_weights(cfg, 5)
+        Bg = cfg.batch_size * world
+        full = O.make_inputs(cfg, Bg, seed=77)
+        shard = {k: torch.tensor(v[rank * cfg.batch_size:(rank + 1) * cfg.batch_size]) for k, v in full.items()}
+        out = T.step_gradients(T.Net(cfg, W, torch.float64), 11, shard)
+        store, g, d, adj = _store(cfg)
+        store.grad = store.grad.double()
+        for m, key in (("G", "dG"), ("D", "dD"), ("A", "dA")):
+            for (s, e), t in zip(store.ranges[m], out[key]):
+                store.grad[s:s + t.numel()] = t.reshape(-1)
+        sync = GradSync("cpu")
+        assert sync.enabled and sync.world_size == world
+        for m in ("D", "G", "A"):  # launch order of the step: D, G, A
+            sync.launch(m, store, *store.model_range(m))
+        sync.wait_all()
+        store.grad /= world
+        if rank == 0:
+            out_q.put(store.grad.numpy().copy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradsync_two_ranks_equals_global_batch():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    cfg = O.Cfg(**CFG)
+    W = O.init_weights(cfg, 5)
+    cfg_g = O.Cfg(**{**CFG, "batch_size": cfg.batch_size * world})
+    full = {k: torch.tensor(v) for k, v in O.make_inputs(cfg, cfg.batch_size * world, seed=77).items()}
+    # the Adjuster branch concatenates along the batch, so the global-batch step must pair samples like the shards do:
+    # evaluate the reference rank by rank on the SAME shards and average (losses are batch means of equal-size shards).
+    ref = None
+    for r in range(world):
+        shard = {k: v[r * cfg.batch_size:(r + 1) * cfg.batch_size] for k, v in full.items()}
+        o = T.step_gradients(T.Net(cfg, W, torch.float64), 11, shard)
+        flat = {m: [t.reshape(-1).numpy() for t in o[k]] for m, k in (("G", "dG"), ("D", "dD"), ("A", "dA"))}
+        ref = flat if ref is None else {m: [a + b for a, b in zip(ref[m], flat[m])] for m in ref}
+    # and, for the G/D tapes (no batch concatenation), directly against ONE process on the concatenated global batch
+    og = T.step_gradients(T.Net(cfg_g, W, torch.float64), 5, full)
+    store, *_ = _store(cfg)
+    for m in "GDA":
+        for i, ((s, e), t) in enumerate(zip(store.ranges[m], ref[m])):
+            assert np.allclose(got[s:s + t.size], t / world, rtol=1e-9, atol=1e-13)
+    for m, key in (("G", "dG"), ("D", "dD")):
+        for (s, e), t in zip(store.ranges[m], og[key]):
+            t = t.reshape(-1).numpy()
+            assert np.allclose(got[s:s + t.size], t, rtol=1e-9, atol=1e-13), (m, np.abs(got[s:s + t.size] - t).max())
