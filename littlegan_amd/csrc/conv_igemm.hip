@@ -17,6 +17,7 @@
 // 16-byte chunk (2q+h) of row r: for f32 that feeds four v_mfma_f32_32x32x2_f32 (k = 8q+4h+j), for
 // bf16 one v_mfma_f32_32x32x16_bf16; A and B use the same k assignment, so the sum is exact.
 // Register-prefetch double buffering: tile k+1's global loads are in flight during tile k's MFMAs.
+#include <stdlib.h>
 #include "lg_common.h"
 
 namespace {
@@ -322,6 +323,15 @@ int dispatch_dtype(const ConvParams& p, int dtype, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const void* wpack, const float* bias, float* out,
+                                int B, int Hm, int Wm, int Cs, int N, int act, void* stream);
+
+static bool halo_enabled() {
+  static int v = -1;
+  if (v < 0) v = getenv("LG_NO_HALO") ? 0 : 1;  // A/B switch: LG_NO_HALO=1 forces the per-tap gather kernel
+  return v == 1;
+}
+
 extern "C" int lg_npad(int n) {
   if (n % 128 == 0) return n;
   if (n % 64 == 0) return n;
@@ -345,6 +355,10 @@ extern "C" int lg_conv_igemm(int mode, int dtype, const float* src, const void* 
   p.pstride = pstride; p.ppad = ppad;
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  if (mode != MODE_PATCH && halo_enabled()) {  // LDS halo-tile kernel where the tiling covers the shape
+    rc = lg_conv_halo_try(mode, dtype, src, wpack, bias, out, B, Hm, Wm, Cs, N, act, stream);
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+  }
   switch (mode) {
     case MODE_DOWN:
       p.Hs = 2 * Hm; p.Ws = 2 * Wm; p.Ho = Hm; p.Wo = Wm;

@@ -224,3 +224,37 @@ def test_clip_adam(ops):
         ops.adam_advance(state, 0.5, 0.9)
     assert np.abs(w.cpu().numpy() - ws[0]).max() < 1e-6
     assert abs(state[0].item() - 0.5 ** 4) < 1e-7
+
+
+HALO_CASES = [  # (mode, B, Hm, Wm, Cs, N): shapes the LDS halo-tile kernel covers (power-of-two maps)
+    ("up", 2, 16, 16, 64, 128), ("up", 3, 8, 8, 128, 64), ("up", 2, 4, 4, 32, 32), ("up", 2, 32, 32, 64, 32),
+    ("up", 2, 16, 16, 64, 3), ("down", 2, 16, 16, 64, 128), ("down", 3, 8, 8, 32, 64), ("down", 1, 32, 16, 32, 32),
+    ("s1t", 2, 16, 16, 32, 3), ("s1t", 1, 32, 32, 32, 3), ("up", 5, 2, 2, 64, 64),
+]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_halo_tile_kernel_matches_oracle(ops, case, dtype):
+    """Same ABI entry points; these shapes route to conv_halo.hip (the gather kernel is covered by the odd shapes)."""
+    mode, B, Hm, Wm, Cs, N = case
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
+    b = r32(rng, N)
+    if mode == "up":      # convT fwd: x [B,Hm,Wm,Cs] -> [B,2Hm,2Wm,N]; kernel [5,5,cb=N,cs=Cs]
+        x, w = r32(rng, B, Hm, Wm, Cs), r32(rng, 5, 5, N, Cs, scale=0.1)
+        if N == 3:        # conv1 data-gradient form (cb == 3): dgrad entry point, no bias
+            got = ops.conv2d_s2_dgrad(dev(x), ops.conv_pack(dev(w), N, Cs, dtype), N, dtype)
+            exp = O.conv_bwd_input(x, w, 2, (2 * Hm, 2 * Wm))
+        else:
+            got = ops.convT_s2_fwd(dev(x), ops.conv_pack(dev(w), N, Cs, dtype), dev(b), N, dtype)
+            exp = O.conv2d_transpose(x, w, b, 2)
+    elif mode == "down":  # conv fwd: x [B,2Hm,2Wm,Cs] -> [B,Hm,Wm,N]; kernel [5,5,cb=Cs,cs=N]
+        x, w = r32(rng, B, 2 * Hm, 2 * Wm, Cs), r32(rng, 5, 5, Cs, N, scale=0.1)
+        got = ops.conv2d_s2_fwd(dev(x), ops.conv_pack(dev(w), Cs, N, dtype), dev(b), N, dtype)
+        exp = O.conv2d(x, w, b, 2)
+    else:                 # final stride-1 convT + tanh
+        x, w = r32(rng, B, Hm, Wm, Cs), r32(rng, 5, 5, N, Cs, scale=0.05)
+        got = ops.convT_s1_tanh_fwd(dev(x), ops.conv_pack(dev(w), N, Cs, dtype), dev(b), N, dtype)
+        exp = np.tanh(O.conv2d_transpose(x, w, b, 1))
+    assert rel(got, exp) < TOL[dtype]
