@@ -94,11 +94,13 @@ def main():
     from littlegan_amd.eager_trainer import EagerTrainer
     from littlegan_amd.model import Adjuster, Decoder, Discriminator, Encoder, Generator
     args = make_args(a.workload, str(device))
-    decoder, encoder = Decoder(args), Encoder(args)
-    gen = Generator(args, decoder)
-    disc = Discriminator(args, encoder)
-    adj = Adjuster(args, disc, gen)
-    tr = EagerTrainer(args, gen, disc, adj, None)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):  # stdout carries exactly ONE JSON line
+        decoder, encoder = Decoder(args), Encoder(args)
+        gen = Generator(args, decoder)
+        disc = Discriminator(args, encoder)
+        adj = Adjuster(args, disc, gen)
+        tr = EagerTrainer(args, gen, disc, adj, None)
     if world > 1:  # identical initial weights on every rank
         import torch.distributed as dist
         dist.broadcast(tr.store.flat, src=0)
