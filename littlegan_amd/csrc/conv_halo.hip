@@ -6,9 +6,12 @@
 // stages the source HALO of that tile once —  (s*TH+E) x (s*TW+E) pixels, E = 2 (UP), 3 (DOWN), 4 (S1T),
 // zero-filled outside the image (TF "SAME") — and then runs ALL taps out of LDS: the MFMA A fragment of
 // (row m, tap t) is halo row  hb(m) + dy_t*HW + dx_t,  a per-lane base plus a wave-uniform offset.
-// Global->LDS activation traffic drops by the tap-reuse factor (UP 9x..4x, DOWN 4.8x, S1T 13x); only the
-// weight tile (B operand, [BN][KC] per tap, double-buffered, register-prefetched) is streamed per tap.
+// Global->LDS activation traffic drops by the tap-reuse factor (UP 9x..4x, DOWN 4.8x, S1T 13x).  The weights (B
+// operand) never touch LDS: the pack is stored in MFMA fragment order (pack.hip), so each wave fetches the 1-KiB
+// operand of an MFMA with one coalesced global_load_dwordx4 per lane, two taps ahead, and the tap loop has NO
+// barrier — the only block-wide synchronisation is the halo restage once per channel chunk.
 // Falls back (LG_ERR_UNSUPPORTED) to the per-tap gather kernel for shapes the tiling does not cover.
+#include <stdlib.h>
 #include "lg_common.h"
 
 namespace {
@@ -27,6 +30,7 @@ struct HaloParams {
   int ntn;
   int TH, TW, NI, tpi_x, tpi;  // tile geometry: tiles per image along x, tiles per image
   int HH, HW, HROWS, nrows;    // halo geometry (per image) and total halo rows
+  int dbg;                     // ablation switches for scripts/bench_layer.py (LG_DBG env; 0 in production)
 };
 
 template <typename T> struct DT;
@@ -52,7 +56,7 @@ __device__ __forceinline__ void tap_info(int mode, int cls, int t, int& dy, int&
   }
 }
 
-template <typename T, int MODE, int KCH, int WAVES_M, int WAVES_N, int MT, int NT>
+template <typename T, int MODE, int KCH, bool DBUF, int WAVES_M, int WAVES_N, int MT, int NT>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
   constexpr int ESZ = DT<T>::ESZ;
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
@@ -61,17 +65,14 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
   constexpr int KC = KCH * 32 / ESZ;
   constexpr int LPR = KC / 4;        // threads per halo row (fp32 source, float4 each)
   constexpr int RPP = 256 / LPR;     // halo rows per pass
-  constexpr int BCH = BN * KCH * 2;  // 16-B chunks in the B tile
-  constexpr int PB = (BCH + 255) / 256;
-  constexpr int B_BYTES = BN * ROWB;
   constexpr int SS = (MODE == MODE_DOWN) ? 2 : 1;
   constexpr int LO = (MODE == MODE_S1T) ? -2 : -1;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sB0 = smem;                                   // [2][BN][ROWB]
-  int* s_out = reinterpret_cast<int*>(smem + 2 * B_BYTES);      // [128]
+  int* s_out = reinterpret_cast<int*>(smem);          // [128]
   int* s_hoff = s_out + BM;                           // [nrows] source pixel index or -1
-  char* sH = smem + 2 * B_BYTES + ((BM + p.nrows) * 4 + 15) / 16 * 16;   // [nrows][ROWB]
+  char* sH = smem + ((BM + p.nrows) * 4 + 15) / 16 * 16;   // [DBUF ? 2 : 1][nrows][ROWB]
+  const int HBYTES = p.nrows * ROWB;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -139,42 +140,33 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int arow = tid / LPR, alc = tid % LPR;
-  u32x4 rb[PB];
+  constexpr int NB = NT * KCH;  // B fragments (1 KiB each, 16 B per lane) of one tap for this wave's NT column tiles
+  u32x4 fb0[NB], fb1[NB], fb2[NB];  // three register sets: fragments are fetched two taps ahead of their use
 
-  auto load_b = [&](int t, int c0) {
+  const int nit = nchunk * ntaps;  // flat (chunk, tap) iteration space
+  const int KB = p.Cs * ESZ / 32, N32 = p.Npad >> 5;
+  const int nt0 = (n0 >> 5) + wn * NT;
+
+  // B operand straight from the fragment-ordered pack: block (tap, n32, kb), lane-contiguous 16 B -> one coalesced
+  // 1-KiB global load per MFMA operand, no LDS round trip and no barrier in the tap loop.
+  auto load_frags = [&](u32x4 (&fb)[NB], int it) {
+    const int cc = it / ntaps, t = it - cc * ntaps;
     int dy, dx, widx;
     tap_info(MODE, cls, t, dy, dx, widx);
 #pragma unroll
-    for (int q = 0; q < PB; ++q) {
-      const int c = q * 256 + tid;
-      if (BCH % 256 == 0 || c < BCH) {
-        const int row = c / (KCH * 2), ch = c % (KCH * 2);
-        const char* g = p.wp + ((long long)(widx * p.Npad + n0 + row) * p.Cs + c0) * ESZ + ch * 16;
-        rb[q] = *reinterpret_cast<const u32x4*>(g);
-      }
-    }
-  };
-  auto store_b = [&](int buf) {
-    char* sB = sB0 + buf * B_BYTES;
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int q = 0; q < PB; ++q) {
-      const int c = q * 256 + tid;
-      if (BCH % 256 == 0 || c < BCH) {
-        const int row = c / (KCH * 2), ch = c % (KCH * 2);
-        *reinterpret_cast<u32x4*>(sB + row * ROWB + ch * 16) = rb[q];
+      for (int q = 0; q < KCH; ++q) {
+        const char* g = p.wp + ((((long long)widx * N32 + nt0 + j) * KB + cc * KCH + q) * 64 + lane) * 16;
+        fb[j * KCH + q] = *reinterpret_cast<const u32x4*>(g);
       }
-    }
   };
-
-  __syncthreads();  // tables visible
-
-  for (int cc = 0; cc < nchunk; ++cc) {
-    const int c0 = cc * KC;
-    // ---- stage the halo of this channel chunk (4 rows in flight per thread) ------------------
-    for (int hr0 = 0; hr0 < p.nrows; hr0 += 4 * RPP) {
-      f32x4 v[4];
+  auto stage_halo = [&](int c0, char* sH) {  // synchronous: up to SU halo rows in flight per thread (one L2/HBM latency
+    constexpr int SU = 12;                   // per SU*RPP rows instead of one per 4*RPP)
+    for (int hr0 = 0; hr0 < p.nrows; hr0 += SU * RPP) {
+      f32x4 v[SU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SU; ++u) {
         const int hr = hr0 + u * RPP + arow;
         v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (hr < p.nrows) {
@@ -183,7 +175,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SU; ++u) {
         const int hr = hr0 + u * RPP + arow;
         if (hr < p.nrows) {
           if constexpr (ESZ == 4) {
@@ -196,48 +188,113 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
         }
       }
     }
-    load_b(0, c0);
-    store_b(0);
-    __syncthreads();
-
-    for (int t = 0; t < ntaps; ++t) {
-      const int buf = t & 1;
-      if (t + 1 < ntaps) load_b(t + 1, c0);
-      int dy, dx, widx;
-      tap_info(MODE, cls, t, dy, dx, widx);
-      const int toff = dy * p.HW + dx;
-      const char* sB = sB0 + buf * B_BYTES + (wn * NT * 32 + r) * ROWB + h * 16;
+  };
+  auto compute = [&](int it, const u32x4 (&fb)[NB], const char* sH) {
+    const int t = it % ntaps;
+    int dy, dx, widx;
+    tap_info(MODE, cls, t, dy, dx, widx);
+    const int toff = dy * p.HW + dx;
 #pragma unroll
-      for (int q = 0; q < KCH; ++q) {
-        if constexpr (ESZ == 4) {
-          f32x4 a[MT], b[NT];
+    for (int q = 0; q < KCH; ++q) {
+      if constexpr (ESZ == 4) {
+        f32x4 a[MT];
 #pragma unroll
-          for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(sH + (hb[i] + toff) * ROWB + h * 16 + q * 32);
+        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(sH + (hb[i] + toff) * ROWB + h * 16 + q * 32);
 #pragma unroll
-          for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(sB + j * 32 * ROWB + q * 32);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-              for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-        } else {
-          bf16x8 a[MT], b[NT];
-#pragma unroll
-          for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sH + (hb[i] + toff) * ROWB + h * 16 + q * 32);
-#pragma unroll
-          for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const bf16x8*>(sB + j * 32 * ROWB + q * 32);
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], __builtin_bit_cast(f32x4, fb[j * KCH + q])[e],
+                                                               acc[i][j], 0, 0, 0);
+      } else {
+        bf16x8 a[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sH + (hb[i] + toff) * ROWB + h * 16 + q * 32);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], __builtin_bit_cast(bf16x8, fb[j * KCH + q]),
+                                                                acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+  // Interleaved halo prefetch (DBUF): while the taps of chunk c run out of halo buffer `hcur`, the halo of chunk c+1
+  // is fetched in `upt` row-units per tap (registers for one tap, then into the other buffer) -> no exposed staging.
+  constexpr int UMAX = 4;
+  const int NU = (p.nrows + RPP - 1) / RPP;                                   // row units (one float4 per thread each)
+  const int upt = ntaps > 1 ? (NU + ntaps - 2) / (ntaps - 1) : NU;            // issued during taps 0 .. ntaps-2
+  f32x4 hreg[UMAX];
+  auto halo_issue = [&](int c0, int u0) {
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+      if (u < upt) {
+        const int hr = (u0 + u) * RPP + arow;
+        hreg[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (hr < p.nrows) {
+          const int o = s_hoff[hr];
+          if (o >= 0) hreg[u] = *reinterpret_cast<const f32x4*>(p.src + (long long)o * p.Cs + c0 + alc * 4);
         }
       }
-      if (t + 1 < ntaps) store_b(buf ^ 1);
-      __syncthreads();  // B[buf^1] complete; after the last tap: every wave is done with the halo
     }
+  };
+  auto halo_commit = [&](char* dst, int u0) {
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+      if (u < upt) {
+        const int hr = (u0 + u) * RPP + arow;
+        if (hr < p.nrows) {
+          if constexpr (ESZ == 4) {
+            *reinterpret_cast<f32x4*>(dst + hr * ROWB + alc * 16) = hreg[u];
+          } else {
+            bf16x4 w;
+            w[0] = (__bf16)hreg[u][0]; w[1] = (__bf16)hreg[u][1]; w[2] = (__bf16)hreg[u][2]; w[3] = (__bf16)hreg[u][3];
+            *reinterpret_cast<bf16x4*>(dst + hr * ROWB + alc * 8) = w;
+          }
+        }
+      }
+    }
+  };
+
+  // one tap: MFMAs out of `cur`, then refill `cur` with the fragments of tap it+3 (its MFMAs have been issued, in
+  // order, so the registers are free).  Chunk boundary: every wave must be done with the old halo (barrier).
+  int hsel = 0;
+  auto iteration = [&](int it, u32x4 (&cur)[NB]) {
+    const int cc = it / ntaps, t = it - cc * ntaps;
+    char* hcur = sH + hsel * HBYTES;
+    if constexpr (DBUF) {
+      if (cc + 1 < nchunk && !(p.dbg & 4)) {
+        char* hnext = sH + (hsel ^ 1) * HBYTES;
+        if (t > 0) halo_commit(hnext, (t - 1) * upt);
+        if (t + 1 < ntaps || ntaps == 1) halo_issue((cc + 1) * KC, t * upt);
+        if (ntaps == 1) halo_commit(hnext, 0);
+      }
+    }
+    if (!(p.dbg & 1)) compute(it, cur, hcur);
+    if (it + 3 < nit && !(p.dbg & 2)) load_frags(cur, it + 3);
+    if (t + 1 == ntaps && it + 1 < nit && !(p.dbg & 4)) {
+      __syncthreads();
+      if constexpr (DBUF) {
+        hsel ^= 1;
+      } else {
+        stage_halo((cc + 1) * KC, sH);
+        __syncthreads();
+      }
+    }
+  };
+
+  __syncthreads();  // tables visible
+  load_frags(fb0, 0);
+  if (nit > 1) load_frags(fb1, 1);
+  if (nit > 2) load_frags(fb2, 2);
+  stage_halo(0, sH);
+  __syncthreads();
+  for (int it = 0; it < nit; it += 3) {
+    iteration(it, fb0);
+    if (it + 1 < nit) iteration(it + 1, fb1);
+    if (it + 2 < nit) iteration(it + 2, fb2);
   }
 
   // ---- epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----------
@@ -262,17 +319,22 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
   }
 }
 
-constexpr int LDS_BUDGET = 78 * 1024;  // two blocks per CU (160 KiB)
+constexpr int LDS_BUDGET = 80 * 1024;  // two blocks per CU (160 KiB)
 
-template <typename T, int MODE, int KCH, int WAVES_M, int WAVES_N, int MT, int NT>
+template <typename T, int MODE, int KCH, bool DBUF, int WAVES_M, int WAVES_N, int MT, int NT>
 int launch(HaloParams p, hipStream_t st) {
   constexpr int BN = WAVES_N * NT * 32, ROWB = KCH * 32 + 16;
-  const size_t lds = 2 * (size_t)BN * ROWB + ((128 + p.nrows) * 4 + 15) / 16 * 16 + (size_t)p.nrows * ROWB;
+  const size_t lds = ((128 + p.nrows) * 4 + 15) / 16 * 16 + (size_t)p.nrows * ROWB * (DBUF ? 2 : 1);
   if (lds > LDS_BUDGET) return LG_ERR_UNSUPPORTED;
+  if (DBUF) {  // the interleaved prefetch must fit its register window: ceil(NU/(ntaps-1)) <= 4 with the fewest taps
+    constexpr int KC = KCH * 32 / DT<T>::ESZ, RPP = 256 / (KC / 4);
+    const int NU = (p.nrows + RPP - 1) / RPP, min_taps = MODE == MODE_UP ? 4 : 25;
+    if ((NU + min_taps - 2) / (min_taps - 1) > 4) return LG_ERR_UNSUPPORTED;
+  }
   p.ntn = p.Npad / BN;
   const int ntm = p.NI == 1 ? p.B * p.tpi : lg_cdiv(p.B, p.NI);
   dim3 grid(ntm * p.ntn, MODE == MODE_UP ? 4 : 1);
-  auto kern = conv_halo_kernel<T, MODE, KCH, WAVES_M, WAVES_N, MT, NT>;
+  auto kern = conv_halo_kernel<T, MODE, KCH, DBUF, WAVES_M, WAVES_N, MT, NT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET);
@@ -282,11 +344,18 @@ int launch(HaloParams p, hipStream_t st) {
   return LG_OK;
 }
 
+template <typename T, int MODE, int KCH, bool DBUF>
+int dispatch_bn2(const HaloParams& p, hipStream_t st) {
+  if (p.Npad % 128 == 0) return launch<T, MODE, KCH, DBUF, 2, 2, 2, 2>(p, st);
+  if (p.Npad % 64 == 0) return launch<T, MODE, KCH, DBUF, 2, 2, 2, 1>(p, st);
+  return launch<T, MODE, KCH, DBUF, 4, 1, 1, 1>(p, st);
+}
 template <typename T, int MODE, int KCH>
 int dispatch_bn(const HaloParams& p, hipStream_t st) {
-  if (p.Npad % 128 == 0) return launch<T, MODE, KCH, 2, 2, 2, 2>(p, st);
-  if (p.Npad % 64 == 0) return launch<T, MODE, KCH, 2, 2, 2, 1>(p, st);
-  return launch<T, MODE, KCH, 4, 1, 1, 1>(p, st);
+  int rc = LG_ERR_UNSUPPORTED;
+  if ((p.dbg & 64) && p.Cs / (KCH * 32 / DT<T>::ESZ) > 1) rc = dispatch_bn2<T, MODE, KCH, true>(p, st);  // double-buffered halo: measured slower, opt-in
+  if (rc == LG_ERR_UNSUPPORTED) rc = dispatch_bn2<T, MODE, KCH, false>(p, st);
+  return rc;
 }
 
 template <int MODE>
@@ -326,6 +395,11 @@ extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const voi
   p.B = B; p.Cs = Cs; p.Hm = Hm; p.Wm = Wm; p.N = N; p.Npad = lg_npad(N); p.act = act;
   p.Hs = ss * Hm; p.Ws = ss * Wm;
   p.Ho = mode == MODE_UP ? 2 * Hm : Hm; p.Wo = mode == MODE_UP ? 2 * Wm : Wm;
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("LG_DBG"); dbg = e ? atoi(e) : 0; }
+    p.dbg = dbg;
+  }
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (mode == MODE_DOWN) rc = dispatch<MODE_DOWN>(p, dtype, st);

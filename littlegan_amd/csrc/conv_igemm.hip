@@ -13,7 +13,7 @@
 // GEMM view: M = pixels of the "M grid", N = output channels, K = taps x source channels.
 // A (activations) is gathered from fp32 NHWC global memory, optionally converted to bf16, and staged
 // in LDS as rows of KCH*32 payload bytes (+16 B pad => conflict-free ds_read_b128).  B (weights) comes
-// pre-packed as [tap][Npad][K-contiguous] in the compute dtype (pack.hip).  Lane (r,h) of a wave reads
+// pre-packed in MFMA fragment order in the compute dtype (pack.hip).  Lane (r,h) of a wave reads
 // 16-byte chunk (2q+h) of row r: for f32 that feeds four v_mfma_f32_32x32x2_f32 (k = 8q+4h+j), for
 // bf16 one v_mfma_f32_32x32x16_bf16; A and B use the same k assignment, so the sum is exact.
 // Register-prefetch double buffering: tile k+1's global loads are in flight during tile k's MFMAs.
@@ -182,7 +182,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const int c = q * 256 + tid;
         if (BCH % 256 == 0 || c < BCH) {
           const int row = c / (KCH * 2), ch = c % (KCH * 2);
-          const char* g = p.wp + ((long long)(widx * p.Npad + n0 + row) * p.Cs + c0) * ESZ + ch * 16;
+          // fragment-ordered pack: 16-B piece (row n, k-chunk kc16) lives in block (n/32, kc16/2) at lane 32*(kc16&1) + n%32
+          const int n = n0 + row, kc16 = (c0 * ESZ) / 16 + ch;
+          const char* g = p.wp + ((((long long)widx * (p.Npad >> 5) + (n >> 5)) * (p.Cs * ESZ / 32) + (kc16 >> 1)) * 64 +
+                                  (kc16 & 1) * 32 + (n & 31)) * 16;
           rb[q] = *reinterpret_cast<const u32x4*>(g);
         }
       }

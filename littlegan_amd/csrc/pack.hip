@@ -1,15 +1,34 @@
 // Weight packing: fp32 master kernels [5][5][Cb][Cs] (TF HWIO for Conv2D with Cb=in,Cs=out;
 // TF HWOI for Conv2DTranspose with Cb=out,Cs=in — /root/reference/model.py:15,39-40,86-87)
-// -> MFMA B-operand images [tap][Npad][K contiguous] in the compute dtype.
-//   down pack: n = Cs index, k = Cb index   (conv fwd / convT dgrad)      [25][npad(Cs)][Cb]
-//              Cb == 3: patch form [5][npad(Cs)][16], k = kx*3+c, k=15 zero
-//   up pack  : n = Cb index, k = Cs index   (convT fwd / conv dgrad)      [25][npad(Cb)][Cs]
+// -> MFMA B-operand images in the compute dtype, FRAGMENT-ORDERED (see fo_decode): [tap][n/32][k/EPB][lane][EPL].
+//   down pack: n = Cs index, k = Cb index   (conv fwd / convT dgrad)
+//              Cb == 3: patch form [5][npad(Cs)][16] row-major, k = kx*3+c, k=15 zero
+//   up pack  : n = Cb index, k = Cs index   (convT fwd / conv dgrad)
 // One pack per layer per step (weights change every step); ~90 MB of traffic for the whole model.
 #include "lg_common.h"
 
 extern "C" int lg_npad(int n);
 
 namespace {
+
+// Fragment order: one 1-KiB block = the B operand of ONE MFMA (32 n x 16 k bf16, or 32 n x 8 k f32), stored in lane
+// order (lane = 32*h + r holds n = 32*n32 + r, k = EPB*kb + EPL*h + j, j < EPL) so that a wave fetches it with one
+// fully coalesced global_load_dwordx4.  Layout [tap][n32][kb][lane][EPL].
+template <typename T>
+__device__ __forceinline__ void fo_decode(long long i, int npad, int K, int& t, int& n, int& k) {
+  constexpr int EPL = 16 / (int)sizeof(T);  // elements per lane (16 B)
+  constexpr int EPB = 2 * EPL;              // k elements per block
+  const int j = (int)(i % EPL);
+  long long rem = i / EPL;
+  const int lane = (int)(rem % 64); rem /= 64;
+  const int KB = K / EPB;
+  const int kb = (int)(rem % KB); rem /= KB;
+  const int N32 = npad / 32;
+  const int n32 = (int)(rem % N32);
+  t = (int)(rem / N32);
+  n = n32 * 32 + (lane & 31);
+  k = kb * EPB + (lane >> 5) * EPL + j;
+}
 
 template <typename T>
 __global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ down, T* __restrict__ up, int Cb, int Cs,
@@ -23,18 +42,16 @@ __global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ down, T
         const long long rem = i / 16;
         const int n = (int)(rem % npad_s), ky = (int)(rem / npad_s);
         if (j < 15 && n < Cs) v = w[((long long)(ky * 5 + j / 3) * 3 + (j % 3)) * Cs + n];
-      } else {  // [25][npad_s][Cb]
-        const int k = (int)(i % Cb);
-        const long long rem = i / Cb;
-        const int n = (int)(rem % npad_s), t = (int)(rem / npad_s);
+      } else {  // fragment-ordered [25][npad_s/32][Cb/EPB][64 lanes][EPL]: (n, k) = (cs index, cb index)
+        int t, n, k;
+        fo_decode<T>(i, npad_s, Cb, t, n, k);
         if (n < Cs) v = w[((long long)t * Cb + k) * Cs + n];
       }
       down[i] = (T)v;
-    } else {  // [25][npad_b][Cs]
+    } else {  // fragment-ordered [25][npad_b/32][Cs/EPB][64][EPL]: (n, k) = (cb index, cs index)
       const long long u = i - n_down;
-      const int k = (int)(u % Cs);
-      const long long rem = u / Cs;
-      const int n = (int)(rem % npad_b), t = (int)(rem / npad_b);
+      int t, n, k;
+      fo_decode<T>(u, npad_b, Cs, t, n, k);
       float v = 0.f;
       if (n < Cb) v = w[((long long)t * Cb + n) * Cs + k];
       up[u] = (T)v;
