@@ -1,6 +1,7 @@
 // Typed C-ABI entry points (include/littlegan_hip.h) on top of the shared kernels.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "lg_common.h"
 #include "../../include/littlegan_hip.h"
 
@@ -18,6 +19,18 @@ extern "C" int lg_abi_version(void) { return LG_ABI_VERSION; }
 extern "C" int lg_conv_igemm(int mode, int dtype, const float* src, const void* wpack, const float* bias, float* out,
                              int B, int Hm, int Wm, int Cs, int N, int act, int pstride, int ppad, void* stream);
 extern "C" size_t lg_conv_pack_up_offset(int cb, int cs, int dtype);
+extern "C" size_t lg_conv_pack_raw_offset(int cb, int cs, int dtype);
+extern "C" int lg_n3_s1t_fwd_try(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C,
+                                 void* stream);
+extern "C" int lg_n3_up_try(const float* src, const float* w, float* out, int B, int H, int W, int C, void* stream);
+static bool n3_enabled() {
+  static int v = -1;
+  if (v < 0) v = getenv("LG_NO_N3") ? 0 : 1;  // A/B switch
+  return v == 1;
+}
+static inline const float* raw_pack(const void* pack, int cb, int cs, int dtype) {
+  return (const float*)((const char*)pack + lg_conv_pack_raw_offset(cb, cs, dtype));
+}
 extern "C" int lg_conv_wgrad(const float* big, const float* small, float* dw, void* workspace, size_t ws_bytes, int B,
                              int Hm, int Wm, int cb, int cs, int pstride, int ppad, int accumulate, int dtype,
                              void* stream);
@@ -37,6 +50,10 @@ static int run_down(const float* big, const void* pack, const float* bias, float
 // "up": small [B,Hs,Ws,cs] -> big [B,2Hs,2Ws,cb]
 static int run_up(const float* small, const void* pack, const float* bias, float* big, int B, int Hs, int Ws, int cb,
                   int cs, int dtype, void* stream) {
+  if (cb == 3 && !bias && n3_enabled()) {  // image-side data gradient: VALU kernel, exact f32 in both dtypes
+    const int rc = lg_n3_up_try(small, raw_pack(pack, cb, cs, dtype), big, B, Hs, Ws, cs, stream);
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+  }
   return lg_conv_igemm(MODE_UP, dtype, small, up_pack(pack, cb, cs, dtype), bias, big, B, Hs, Ws, cs, cb, 0, 0, 0,
                        stream);
 }
@@ -68,6 +85,10 @@ extern "C" int lg_convT_s2_wgrad(const float* x, const float* dy, float* dw, voi
 
 extern "C" int lg_convT_s1_tanh_fwd(const float* x, const void* pack, const float* bias, float* y, int B, int H, int W,
                                     int cb, int cs, int dtype, void* stream) {
+  if (cb == 3 && n3_enabled()) {
+    const int rc = lg_n3_s1t_fwd_try(x, raw_pack(pack, cb, cs, dtype), bias, y, B, H, W, cs, stream);
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+  }
   return lg_conv_igemm(MODE_S1T, dtype, x, up_pack(pack, cb, cs, dtype), bias, y, B, H, W, cs, cb, 1, 0, 0, stream);
 }
 

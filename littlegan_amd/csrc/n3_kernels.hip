@@ -1,0 +1,269 @@
+// The 3-channel ("image side") layers of LittleGAN: 2 % of the step's FLOPs but, run through 32-wide MFMA tiles,
+// a quarter of its time.  N = 3 output channels waste 29/32 of every MFMA, so these kernels use the VALU for the
+// two forward-shaped ops (weights are wave-uniform -> they stream through SGPRs, activations come from an LDS halo
+// tile) and the exact-f32 MFMA for the weight gradients (all 25 taps per pixel tile, operands gathered from LDS).
+//   n3_s1t_fwd : y[B,H,W,3] = tanh(convT_s1(x[B,H,W,C]) + b)            /root/reference/model.py:86-87,104
+//   n3_up      : dimg[B,2H,2W,3] = conv2d_backprop_input(dz[B,H,W,C])   (gradient of Encoder.conv1, model.py:15)
+//   n3_wgrad   : dW[5][5][3][C] (+)= sum big3[s*o + k - pad][c3] * small[o][c]   (conv1: s=2,pad=1; final: s=1,pad=2)
+#include "lg_common.h"
+
+namespace {
+
+// --------------------------------------------------------------------------------------------------------------
+// forward-shaped, 16x16 pixel tile per 256-thread block, one thread per (tile) pixel
+// --------------------------------------------------------------------------------------------------------------
+constexpr int TS = 16;
+
+template <int C>
+__global__ __launch_bounds__(256) void n3_s1t_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                         int H, int W) {
+  constexpr int HS = TS + 4, ROWF = C + 4;  // halo side, floats per halo pixel (16-B pad: conflict-free b128 reads)
+  extern __shared__ __attribute__((aligned(16))) float halo[];  // [HS*HS][ROWF]
+  const int tpx = W / TS, tpi = tpx * (H / TS);
+  const int n = blockIdx.x / tpi, tt = blockIdx.x % tpi;
+  const int y0 = (tt / tpx) * TS, x0 = (tt % tpx) * TS;
+  for (int i = threadIdx.x; i < HS * HS * (C / 4); i += 256) {
+    const int hp = i / (C / 4), c4 = i % (C / 4);
+    const int sy = y0 - 2 + hp / HS, sx = x0 - 2 + hp % HS;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W)
+      v = *reinterpret_cast<const f32x4*>(x + ((long long)(n * H + sy) * W + sx) * C + c4 * 4);
+    *reinterpret_cast<f32x4*>(halo + hp * ROWF + c4 * 4) = v;
+  }
+  __syncthreads();
+  const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
+  float acc[3] = {bias[0], bias[1], bias[2]};
+#pragma unroll 1
+  for (int ky = 0; ky < 5; ++ky) {
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) {
+      // y[o] = sum_k x[o + 2 - k] W[k]: halo pixel (ly + 2 + (2-ky), lx + 2 + (2-kx)) in halo coords offset by -2
+      const float* hp = halo + ((ly + 4 - ky) * HS + (lx + 4 - kx)) * ROWF;
+      const float* wt = w + (ky * 5 + kx) * 3 * C;  // [co][c], wave-uniform -> scalar loads
+#pragma unroll
+      for (int c4 = 0; c4 < C / 4; ++c4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(hp + c4 * 4);
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+          const float* wc = wt + co * C + c4 * 4;
+          acc[co] = fmaf(v[0], wc[0], acc[co]); acc[co] = fmaf(v[1], wc[1], acc[co]);
+          acc[co] = fmaf(v[2], wc[2], acc[co]); acc[co] = fmaf(v[3], wc[3], acc[co]);
+        }
+      }
+    }
+  }
+  float* o = y + ((long long)(n * H + y0 + ly) * W + x0 + lx) * 3;
+  o[0] = tanhf(acc[0]); o[1] = tanhf(acc[1]); o[2] = tanhf(acc[2]);
+}
+
+// one thread per SOURCE pixel q of a 16x16 tile; it owns the 2x2 output quad (4 parity classes x 3 channels)
+template <int CK>  // channels per LDS chunk
+__global__ __launch_bounds__(256) void n3_up_kernel(const float* __restrict__ src, const float* __restrict__ w,
+                                                    float* __restrict__ out, int B, int H, int W, int C) {
+  constexpr int HS = TS + 2, ROWF = CK + 4;
+  extern __shared__ __attribute__((aligned(16))) float halo[];  // [HS*HS][ROWF]
+  const int tpx = W / TS, tpi = tpx * (H / TS);
+  const int n = blockIdx.x / tpi, tt = blockIdx.x % tpi;
+  const int y0 = (tt / tpx) * TS, x0 = (tt % tpx) * TS;
+  const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
+  float acc[4][3];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { acc[k][0] = 0.f; acc[k][1] = 0.f; acc[k][2] = 0.f; }
+  for (int c0 = 0; c0 < C; c0 += CK) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < HS * HS * (CK / 4); i += 256) {
+      const int hp = i / (CK / 4), c4 = i % (CK / 4);
+      const int sy = y0 - 1 + hp / HS, sx = x0 - 1 + hp % HS;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W)
+        v = *reinterpret_cast<const f32x4*>(src + ((long long)(n * H + sy) * W + sx) * C + c0 + c4 * 4);
+      *reinterpret_cast<f32x4*>(halo + hp * ROWF + c4 * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) {
+        // out[2q+p] += src[q + d] W[k],  p = 1 - (k & 1),  d = (p + 1 - k) / 2   (conv2d_backprop_input, SAME, s=2, k=5)
+        const int py = 1 - (ky & 1), px = 1 - (kx & 1);
+        const int dy = (py + 1 - ky) / 2, dx = (px + 1 - kx) / 2;
+        const int cls = py * 2 + px;
+        const float* hp = halo + ((ly + 1 + dy) * HS + (lx + 1 + dx)) * ROWF;
+        const float* wt = w + ((ky * 5 + kx) * 3) * C + c0;  // [cb=3][cs=C] rows
+#pragma unroll
+        for (int c4 = 0; c4 < CK / 4; ++c4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(hp + c4 * 4);
+#pragma unroll
+          for (int co = 0; co < 3; ++co) {
+            const float* wc = wt + co * C + c4 * 4;
+            float a = acc[cls][co];
+            a = fmaf(v[0], wc[0], a); a = fmaf(v[1], wc[1], a); a = fmaf(v[2], wc[2], a); a = fmaf(v[3], wc[3], a);
+            acc[cls][co] = a;
+          }
+        }
+      }
+    }
+  }
+  const int y = y0 + ly, xq = x0 + lx;
+#pragma unroll
+  for (int py = 0; py < 2; ++py) {
+    float* o = out + ((long long)(n * 2 * H + 2 * y + py) * 2 * W + 2 * xq) * 3;
+#pragma unroll
+    for (int px = 0; px < 2; ++px)
+#pragma unroll
+      for (int co = 0; co < 3; ++co) o[px * 3 + co] = acc[py * 2 + px][co];
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// weight gradient of a 3-channel layer, all 25 taps at once.  GEMM: M = 75 (tap, c3) -> 3 MFMA row tiles,
+// N = Cs (1 or 2 column tiles), K = pixels of the small grid.  A[i][k] is GATHERED from an LDS halo of the
+// 3-channel tensor (per-lane row offset + per-k pixel base), B[k][j] is the small tensor's pixel row.
+// Block = 4 waves, pixel tile 8x16: wave w reduces pixels [32w, 32w+32) and writes its own fp32 slab.
+// --------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void n3_wgrad_kernel(const float* __restrict__ big3, const float* __restrict__ small,
+                                                       float* __restrict__ slab, int B, int H, int W, int s, int pad) {
+  constexpr int Cs = NT * 32, TH = 8, TW = 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int HH = s * TH + 4, HW = s * TW + 4;  // halo of the 3-channel tensor (taps span 5 pixels)
+  float* sB = smem;                            // [128][Cs]
+  float* sA = smem + TH * TW * Cs;             // [HH*HW*3] (+ 1 zero)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int tpx = W / TW, tpi = tpx * (H / TH), ntiles = B * tpi;
+  const int Hb = s * H, Wb = s * W;
+  int aoff[3];
+  bool aval[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int idx = i * 32 + r;  // (tap, c3)
+    aval[i] = idx < 75;
+    const int t = idx / 3, c3 = idx - t * 3;
+    aoff[i] = aval[i] ? ((t / 5) * HW + (t % 5)) * 3 + c3 : 0;
+  }
+  f32x16 acc[3][NT];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / tpi, tt = tile - n * tpi;
+    const int y0 = (tt / tpx) * TH, x0 = (tt % tpx) * TW;
+    __syncthreads();
+    for (int i = threadIdx.x; i < TH * TW * (Cs / 4); i += 256) {
+      const int pix = i / (Cs / 4), c4 = i % (Cs / 4);
+      const int yy = y0 + pix / TW, xx = x0 + pix % TW;
+      *reinterpret_cast<f32x4*>(sB + pix * Cs + c4 * 4) =
+          *reinterpret_cast<const f32x4*>(small + ((long long)(n * H + yy) * W + xx) * Cs + c4 * 4);
+    }
+    for (int i = threadIdx.x; i < HH * HW * 3; i += 256) {
+      const int hp = i / 3, c3 = i - hp * 3;
+      const int sy = s * y0 - pad + hp / HW, sx = s * x0 - pad + hp % HW;
+      float v = 0.f;
+      if ((unsigned)sy < (unsigned)Hb && (unsigned)sx < (unsigned)Wb) v = big3[((long long)(n * Hb + sy) * Wb + sx) * 3 + c3];
+      sA[i] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+      const int m = wid * 32 + 2 * kk + h;  // pixel of this lane's k
+      const int ly = m / TW, lx = m % TW;
+      const int pbase = ((s * ly) * HW + s * lx) * 3;
+      float a[3], b[NT];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) a[i] = aval[i] ? sA[pbase + aoff[i]] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = sB[m * Cs + j * 32 + r];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* o = slab + (long long)(blockIdx.x * 4 + wid) * 75 * Cs;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < 75) o[row * Cs + j * 32 + r] = acc[i][j][e];
+      }
+}
+
+__global__ void n3_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslab, int n,
+                                      int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = accumulate ? dw[i] : 0.f;
+  for (int k = 0; k < nslab; ++k) s += slab[(long long)k * n + i];
+  dw[i] = s;
+}
+
+inline int wgrad_blocks(int ntiles) { return ntiles < 512 ? ntiles : 512; }
+
+}  // namespace
+
+// ---- entry points used by conv_igemm.hip / wgrad_igemm.hip / capi.hip (LG_ERR_UNSUPPORTED -> generic kernels) ----
+extern "C" int lg_n3_s1t_fwd_try(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C,
+                                 void* stream) {
+  if (H % TS || W % TS || !bias || !w) return LG_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = B * (H / TS) * (W / TS);
+  if (C == 32) {
+    const size_t lds = (size_t)(TS + 4) * (TS + 4) * (32 + 4) * 4;
+    static bool a = false;
+    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(n3_s1t_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a = true; }
+    hipLaunchKernelGGL(n3_s1t_fwd_kernel<32>, dim3(grid), dim3(256), lds, st, x, w, bias, y, B, H, W);
+  } else if (C == 64) {
+    const size_t lds = (size_t)(TS + 4) * (TS + 4) * (64 + 4) * 4;
+    static bool a = false;
+    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(n3_s1t_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a = true; }
+    hipLaunchKernelGGL(n3_s1t_fwd_kernel<64>, dim3(grid), dim3(256), lds, st, x, w, bias, y, B, H, W);
+  } else {
+    return LG_ERR_UNSUPPORTED;
+  }
+  LG_CHECK_LAUNCH("lg_n3_s1t_fwd");
+  return LG_OK;
+}
+
+extern "C" int lg_n3_up_try(const float* src, const float* w, float* out, int B, int H, int W, int C, void* stream) {
+  if (H % TS || W % TS || C % 32 || !w) return LG_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)(TS + 2) * (TS + 2) * (32 + 4) * 4;
+  hipLaunchKernelGGL(n3_up_kernel<32>, dim3(B * (H / TS) * (W / TS)), dim3(256), lds, (hipStream_t)stream, src, w, out, B,
+                     H, W, C);
+  LG_CHECK_LAUNCH("lg_n3_up");
+  return LG_OK;
+}
+
+extern "C" size_t lg_n3_wgrad_workspace_bytes(int B, int H, int W, int Cs) {
+  const int ntiles = B * (H / 8) * (W / 16);
+  return (size_t)wgrad_blocks(ntiles > 0 ? ntiles : 1) * 4 * 75 * Cs * sizeof(float);
+}
+
+extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, float* dw, void* workspace, size_t ws_bytes, int B,
+                               int H, int W, int Cs, int s, int pad, int accumulate, void* stream) {
+  if (H % 8 || W % 16 || (Cs != 32 && Cs != 64) || (s != 1 && s != 2)) return LG_ERR_UNSUPPORTED;
+  if (ws_bytes < lg_n3_wgrad_workspace_bytes(B, H, W, Cs)) return LG_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int ntiles = B * (H / 8) * (W / 16), nblk = wgrad_blocks(ntiles);
+  const size_t lds = (size_t)(128 * Cs + (s * 8 + 4) * (s * 16 + 4) * 3 + 4) * 4;
+  if (Cs == 32) {
+    hipLaunchKernelGGL(n3_wgrad_kernel<1>, dim3(nblk), dim3(256), lds, st, big3, small, (float*)workspace, B, H, W, s, pad);
+  } else {
+    static bool a = false;
+    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(n3_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); a = true; }
+    hipLaunchKernelGGL(n3_wgrad_kernel<2>, dim3(nblk), dim3(256), lds, st, big3, small, (float*)workspace, B, H, W, s, pad);
+  }
+  LG_CHECK_LAUNCH("lg_n3_wgrad");
+  const int n = 75 * Cs;
+  hipLaunchKernelGGL(n3_slab_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)workspace, dw, nblk * 4, n,
+                     accumulate);
+  LG_CHECK_LAUNCH("lg_n3_wgrad(reduce)");
+  return LG_OK;
+}

@@ -72,9 +72,14 @@ extern "C" size_t lg_conv_pack_up_offset(int cb, int cs, int dtype) {
   return (down_elems(cb, cs) * esz + 255) / 256 * 256;
 }
 
-extern "C" size_t lg_conv_pack_bytes(int cb, int cs, int dtype) {
+// cb == 3 layers also carry a verbatim fp32 copy of the kernel [5][5][3][cs] for the VALU kernels of n3_kernels.hip
+extern "C" size_t lg_conv_pack_raw_offset(int cb, int cs, int dtype) {
   const size_t esz = dtype == LG_DT_F32 ? 4 : 2;
   return lg_conv_pack_up_offset(cb, cs, dtype) + (up_elems(cb, cs) * esz + 255) / 256 * 256;
+}
+
+extern "C" size_t lg_conv_pack_bytes(int cb, int cs, int dtype) {
+  return lg_conv_pack_raw_offset(cb, cs, dtype) + (cb == 3 ? ((size_t)75 * cs * 4 + 255) / 256 * 256 : 0);
 }
 
 extern "C" int lg_conv_pack(const float* w, void* pack, int cb, int cs, int dtype, void* stream) {
@@ -93,5 +98,10 @@ extern "C" int lg_conv_pack(const float* w, void* pack, int cb, int cs, int dtyp
     hipLaunchKernelGGL(pack_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, w, (__bf16*)pack, (__bf16*)up, cb, cs,
                        lg_npad(cs), lg_npad(cb), nd, nu);
   LG_CHECK_LAUNCH("lg_conv_pack");
+  if (cb == 3) {
+    hipError_t e = hipMemcpyAsync((char*)pack + lg_conv_pack_raw_offset(cb, cs, dtype), w, (size_t)75 * cs * 4,
+                                  hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) { lg_set_error("lg_conv_pack: raw copy failed: %s", hipGetErrorString(e)); return LG_ERR_LAUNCH; }
+  }
   return LG_OK;
 }

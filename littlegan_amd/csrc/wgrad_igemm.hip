@@ -8,6 +8,7 @@
 // Both operands are "k-major" in memory (pixel rows, channels contiguous) which is exactly the
 // v_mfma_f32_32x32x2_f32 operand shape: lane (r,h) reads LDS[pixel 2kk+h][channel r].
 // bf16 variant: LDS holds bf16 [pixel][channel]; fragments come from ds_read_b64_tr_b16.
+#include <stdlib.h>
 #include "lg_common.h"
 
 namespace {
@@ -301,7 +302,18 @@ inline int pick_nsplit(int tiles, int M, int KP) {
 
 }  // namespace
 
+extern "C" size_t lg_n3_wgrad_workspace_bytes(int B, int H, int W, int Cs);
+extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, float* dw, void* workspace, size_t ws_bytes, int B,
+                               int H, int W, int Cs, int s, int pad, int accumulate, void* stream);
+static size_t wgrad_ws_generic(int B, int Hm, int Wm, int cb, int cs, int dtype);
+
 extern "C" size_t lg_wgrad_workspace_bytes(int B, int Hm, int Wm, int cb, int cs, int dtype) {
+  size_t g = wgrad_ws_generic(B, Hm, Wm, cb, cs, dtype);
+  if (cb == 3) { const size_t n = lg_n3_wgrad_workspace_bytes(B, Hm, Wm, cs); if (n > g) g = n; }
+  return g;
+}
+
+static size_t wgrad_ws_generic(int B, int Hm, int Wm, int cb, int cs, int dtype) {
   const int KP = dtype == LG_DT_BF16 ? 64 : 32;
   const int cbp = cb == 3 ? 16 : cb, ntaps = cb == 3 ? 5 : 25;
   TileSel ts = pick_tile(cb == 3 ? 32 : cbp, cs);
@@ -320,6 +332,10 @@ extern "C" int lg_conv_wgrad(const float* big, const float* small, float* dw, vo
   LG_CHECK_ARG(B > 0 && Hm > 0 && Wm > 0 && cs % 32 == 0 && (cb == 3 || cb % 32 == 0),
                "lg_conv_wgrad: bad shape B=%d Hm=%d Wm=%d cb=%d cs=%d", B, Hm, Wm, cb, cs);
   LG_CHECK_ARG(ws_bytes >= lg_wgrad_workspace_bytes(B, Hm, Wm, cb, cs, dtype), "lg_conv_wgrad: workspace too small");
+  if (cb == 3 && !getenv("LG_NO_N3")) {  // all-taps 3-channel kernel (n3_kernels.hip) where its tiling applies
+    const int rc = lg_n3_wgrad_try(big, small, dw, workspace, ws_bytes, B, Hm, Wm, cs, pstride, ppad, accumulate, stream);
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+  }
   const bool patch = cb == 3;
   const bool bf16 = dtype == LG_DT_BF16 && !patch;  // patch layers stay on the exact f32 MFMA
   const int KP = bf16 ? 64 : 32;

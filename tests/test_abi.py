@@ -75,6 +75,6 @@ def test_argument_validation_without_gpu(lib):
     assert h.lg_conv_pack_bytes(64, 128, 0) == 2 * 25 * 64 * 128 * 4
     assert h.lg_conv_pack_bytes(64, 128, 1) == 2 * 25 * 64 * 128 * 2
     # cb == 3: patch down pack [5][npad(cs)][16] + up pack [25][32][cs]
-    assert h.lg_conv_pack_bytes(3, 64, 0) == 5 * 64 * 16 * 4 + 25 * 32 * 64 * 4
+    assert h.lg_conv_pack_bytes(3, 64, 0) == 5 * 64 * 16 * 4 + 25 * 32 * 64 * 4 + 75 * 64 * 4  # + verbatim f32 kernel
     with pytest.raises(lib.LittleGanHipError):
         lib.check(-1, "x")

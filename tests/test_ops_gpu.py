@@ -36,7 +36,7 @@ def r32(rng, *shape, scale=1.0):
 
 S2_CASES = [  # (B, Hs, Ws, cb, cs)
     (3, 5, 6, 32, 64), (2, 8, 9, 64, 128), (2, 4, 4, 128, 32), (2, 3, 3, 256, 384), (3, 7, 5, 3, 64), (2, 6, 6, 3, 32),
-    (1, 16, 16, 32, 32),
+    (1, 16, 16, 32, 32), (2, 8, 16, 3, 64), (1, 16, 16, 3, 32), (2, 16, 32, 3, 64),
 ]
 
 
