@@ -19,11 +19,17 @@ __device__ __forceinline__ float head_w(const float* __restrict__ wpr, const flo
 constexpr int FB = 4;     // samples per block (fwd)
 constexpr int KCH = 256;  // k per LDS chunk
 
+// Both operands of a k-chunk go through LDS with wide coalesced loads: the weight rows wc[k0..k0+255][0..c) are one
+// contiguous 40-KB run (read with float4), wpr[k0..] a 1-KB run; lane j then reads sw[k][j] (consecutive lanes ->
+// consecutive banks) and the activation as a 4-k ds_read_b128 broadcast.
 __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wpr,
                                                         const float* __restrict__ bpr, const float* __restrict__ wc,
                                                         const float* __restrict__ bc, float* __restrict__ p, int B,
                                                         int K, int c) {
-  __shared__ __attribute__((aligned(16))) float xs[FB][KCH];
+  extern __shared__ __attribute__((aligned(16))) float hsm[];
+  float* xs = hsm;                 // [FB][KCH]
+  float* swc = hsm + FB * KCH;     // [KCH][c]  (row k, c floats)
+  float* swp = swc + KCH * c;      // [KCH]
   __shared__ float sred[4][FB][64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int b0 = blockIdx.x * FB;
@@ -31,23 +37,35 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
   float acc[FB];
 #pragma unroll
   for (int b = 0; b < FB; ++b) acc[b] = 0.f;
+  const bool vec_ok = (c % 4 == 0) && ((reinterpret_cast<size_t>(wc) & 15) == 0);
   for (int k0 = 0; k0 < K; k0 += KCH) {
+    const int kn = min(KCH, K - k0);
     __syncthreads();
-    for (int i = threadIdx.x; i < FB * KCH; i += 256) {
-      const int b = i / KCH, kk = i - b * KCH;
-      xs[b][kk] = (b0 + b < B && k0 + kk < K) ? x[(long long)(b0 + b) * K + k0 + kk] : 0.f;
+    for (int i = threadIdx.x; i < FB * KCH / 4; i += 256) {
+      const int b = i / (KCH / 4), k4 = (i % (KCH / 4)) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b0 + b < B && k0 + k4 < K) v = *reinterpret_cast<const f32x4*>(x + (long long)(b0 + b) * K + k0 + k4);
+      *reinterpret_cast<f32x4*>(xs + b * KCH + k4) = v;
     }
+    if (vec_ok) {
+      const f32x4* g = reinterpret_cast<const f32x4*>(wc + (long long)k0 * c);
+      for (int i = threadIdx.x; i < kn * c / 4; i += 256) reinterpret_cast<f32x4*>(swc)[i] = g[i];
+    } else {
+      for (int i = threadIdx.x; i < kn * c; i += 256) swc[i] = wc[(long long)k0 * c + i];
+    }
+    for (int i = threadIdx.x; i < KCH; i += 256) swp[i] = i < kn ? wpr[k0 + i] : 0.f;
+    if (kn < KCH) for (int i = kn * c + threadIdx.x; i < KCH * c; i += 256) swc[i] = 0.f;
     __syncthreads();
     const int kw = wid * 64;  // this wave's 64 k of the chunk
 #pragma unroll 4
     for (int kk = 0; kk < 64; kk += 4) {
-      const int k = k0 + kw + kk;
+      const int k = kw + kk;
       float w[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = (act && k + e < K) ? head_w(wpr, wc, k + e, lane, c) : 0.f;
+      for (int e = 0; e < 4; ++e) w[e] = !act ? 0.f : (lane == 0 ? swp[k + e] : swc[(k + e) * c + lane - 1]);
 #pragma unroll
       for (int b = 0; b < FB; ++b) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs[b][kw + kk]);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + b * KCH + k);
         acc[b] += (xv[0] * w[0] + xv[1] * w[1]) + (xv[2] * w[2] + xv[3] * w[3]);
       }
     }
@@ -148,7 +166,8 @@ extern "C" int lg_heads_fwd(const float* x, const float* wpr, const float* bpr, 
                             float* p, int B, int K, int c, void* stream) {
   LG_CHECK_ARG(x && wpr && bpr && wc && bc && p, "lg_heads_fwd: null pointer");
   LG_CHECK_ARG(B > 0 && K > 0 && K % 4 == 0 && c >= 1 && c <= HC_MAX, "lg_heads_fwd: bad shape B=%d K=%d c=%d", B, K, c);
-  hipLaunchKernelGGL(heads_fwd_kernel, dim3(lg_cdiv(B, FB)), dim3(256), 0, (hipStream_t)stream, x, wpr, bpr, wc, bc, p, B,
+  const size_t lds = (size_t)(FB * KCH + KCH * c + KCH) * sizeof(float);
+  hipLaunchKernelGGL(heads_fwd_kernel, dim3(lg_cdiv(B, FB)), dim3(256), lds, (hipStream_t)stream, x, wpr, bpr, wc, bc, p, B,
                      K, c);
   LG_CHECK_LAUNCH("lg_heads_fwd");
   return LG_OK;

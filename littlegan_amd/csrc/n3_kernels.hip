@@ -196,16 +196,23 @@ __global__ __launch_bounds__(256) void n3_wgrad_kernel(const float* __restrict__
       }
 }
 
-__global__ void n3_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslab, int n,
-                                      int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = accumulate ? dw[i] : 0.f;
-  for (int k = 0; k < nslab; ++k) s += slab[(long long)k * n + i];
-  dw[i] = s;
+// dw[i] (+)= sum_k slab[k][i] : 64 outputs per block, 4 slab lanes per output, coalesced 256-B rows
+__global__ __launch_bounds__(256) void n3_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                             int nslab, int n, int accumulate) {
+  __shared__ float sr[4][64];
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  float s = 0.f;
+  if (o < n)
+    for (int k = g; k < nslab; k += 4) s += slab[(long long)k * n + o];
+  sr[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0 && o < n) {
+    const int l = threadIdx.x & 63;
+    dw[o] = (accumulate ? dw[o] : 0.f) + ((sr[0][l] + sr[1][l]) + (sr[2][l] + sr[3][l]));
+  }
 }
 
-inline int wgrad_blocks(int ntiles) { return ntiles < 512 ? ntiles : 512; }
+inline int wgrad_blocks(int ntiles) { return ntiles < 256 ? ntiles : 256; }
 
 }  // namespace
 
@@ -262,7 +269,7 @@ extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, float* dw,
   }
   LG_CHECK_LAUNCH("lg_n3_wgrad");
   const int n = 75 * Cs;
-  hipLaunchKernelGGL(n3_slab_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)workspace, dw, nblk * 4, n,
+  hipLaunchKernelGGL(n3_slab_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)workspace, dw, nblk * 4, n,
                      accumulate);
   LG_CHECK_LAUNCH("lg_n3_wgrad(reduce)");
   return LG_OK;

@@ -101,7 +101,10 @@ class EagerTrainer:
             adj_in_img = torch.cat([img1, fake], 0)
             adj_t_img = torch.cat([img2, img1], 0)
             ctx_a: dict = {}
-            adj_image = A([adj_in_img, adj_in_cond], ctx_a)
+            # encoder(fake) was computed by D above with the same weights: hand its 4 maps to the Adjuster
+            i_d, f0 = a.init_dim, a.conv_filter[0]
+            tails = [ctx_d["enc"][k][0][B:] for k in (1, 2, 3)] + [ctx_d["heads_x"][B:].view(B, i_d, i_d, f0)]
+            adj_image = A([adj_in_img, adj_in_cond], ctx_a, enc_tails=tails)
             ctx_d2: dict = {}
             p_a = D.forward_packed(adj_image, ctx_d2)
             dz_a = torch.empty(2 * B, 1 + c, dtype=torch.float32, device=self.device)

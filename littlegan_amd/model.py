@@ -117,18 +117,28 @@ class Encoder(_ConvStack):
     def _bias_dim(cb, cs):
         return cs
 
-    def __call__(self, inputs, ctx: Optional[dict] = None):
+    def __call__(self, inputs, ctx: Optional[dict] = None, tails=None):
+        """tails (optional): the 4 maps this encoder already produced for MORE samples that follow `inputs` in the
+        batch (same weights); they are appended to the outputs instead of being recomputed (the Adjuster's input is
+        [img1 ; fake] and D has just encoded `fake`).  Every op is per-sample, so the result is identical."""
         x = inputs
         a = self.args.leaky_alpha
         packs = self.packs()
         outs = []
         saved = []
+        B1 = x.shape[0]
         for i, (cb, cs) in enumerate(self.chans, 1):
             z = ops.conv2d_s2_fwd(x, packs[i - 1], self._w[f"conv{i}.bias"], cs, self.dtype)
             st = ops.instnorm_stats(z, self._w[f"norm{i}.gamma"], self._w[f"norm{i}.beta"], 0, a)
-            h = ops.instnorm_apply(z, st, None, 0, 1, a)
+            if tails is None:
+                h = ops.instnorm_apply(z, st, None, 0, 1, a)
+                outs.append(h)
+            else:
+                full = torch.empty((B1 + tails[i - 1].shape[0],) + tuple(z.shape[1:]), dtype=torch.float32, device=z.device)
+                h = ops.instnorm_apply(z, st, None, 0, 1, a, out=full[:B1])
+                full[B1:].copy_(tails[i - 1])
+                outs.append(full)
             saved.append((x, z, st))
-            outs.append(h)
             x = h
         if ctx is not None:
             ctx["enc"] = saved
@@ -373,9 +383,12 @@ class Adjuster(_Module):
     def weights(self):
         return self.encoder.weights + self._dn.weights + self.decoder.weights + self.conv.weights
 
-    def __call__(self, inputs, ctx: Optional[dict] = None):
+    def __call__(self, inputs, ctx: Optional[dict] = None, enc_tails=None):
         image, cond = inputs
-        enc = self.encoder(image)  # no context: no tape of the step differentiates through it
+        if enc_tails is None:
+            enc = self.encoder(image)  # no context: no tape of the step differentiates through it
+        else:  # the trailing samples of `image` were already encoded by D in this step (same weights): reuse
+            enc = self.encoder(image[:image.shape[0] - enc_tails[0].shape[0]], None, tails=enc_tails)
         c4 = self._dn(cond.contiguous(), ctx)
         x = self.decoder([c4, enc[::-1]], ctx)
         img = self.conv(x)
