@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
   int ntaps;
   if (MODE == MODE_UP) ntaps = (py ? 3 : 2) * (px ? 3 : 2);
   else ntaps = 25;
+  if (p.dbg & 8) ntaps = 1;  // ablation: one tap per chunk -> fixed per-block cost (timing only)
   const int nchunk = p.Cs / KC;
 
   f32x16 acc[MT][NT];
