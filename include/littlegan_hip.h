@@ -44,6 +44,11 @@ int lg_conv_pack(const float* w, void* pack, int cb, int cs, int dtype, void* st
 /* y[B,Hs,Ws,cs] = conv(x[B,2Hs,2Ws,cb]) + bias ; cb == 3 uses the 3-channel patch kernel */
 int lg_conv2d_s2_fwd(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws, int cb,
                      int cs, int dtype, void* stream);
+/* same + fused InstanceNormalization moment partials of y (instance.py:114-115): when the chosen kernel supports it,
+ * *nparts > 0 and spart holds [B][*nparts][3] doubles {count, mean, M2}; finish with lg_instnorm_stats_finalize.
+ * *nparts == 0: not produced, use lg_instnorm_leaky_stats. */
+int lg_conv2d_s2_fwd_stats(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws, int cb,
+                           int cs, int dtype, void* spart, size_t spart_bytes, int* nparts, void* stream);
 /* dx[B,2Hs,2Ws,cb] = conv2d_backprop_input(dy[B,Hs,Ws,cs]) */
 int lg_conv2d_s2_dgrad(const float* dy, const void* pack, float* dx, int B, int Hs, int Ws, int cb, int cs, int dtype,
                        void* stream);
@@ -55,6 +60,8 @@ int lg_conv2d_s2_wgrad(const float* x, const float* dy, float* dw, void* workspa
 /* y[B,2Hs,2Ws,cb] = convT(x[B,Hs,Ws,cs]) + bias   (4-phase sub-pixel implicit GEMM) */
 int lg_convT_s2_fwd(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws, int cb,
                     int cs, int dtype, void* stream);
+int lg_convT_s2_fwd_stats(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws, int cb,
+                          int cs, int dtype, void* spart, size_t spart_bytes, int* nparts, void* stream);
 int lg_convT_s2_dgrad(const float* dy, const void* pack, float* dx, int B, int Hs, int Ws, int cb, int cs, int dtype,
                       void* stream);
 int lg_convT_s2_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t ws_bytes, int B, int Hs,
@@ -83,6 +90,8 @@ size_t lg_instnorm_workspace_bytes(int B, long long L);
 int lg_instnorm_stats_stride(void);
 int lg_instnorm_leaky_stats(const float* x, float* stats, const float* gamma, const float* beta, void* workspace,
                             size_t ws_bytes, int B, long long L, int pre_leaky, float alpha, void* stream);
+int lg_instnorm_stats_finalize(const void* partials, int nparts, float* stats, const float* gamma, const float* beta,
+                               int B, void* stream);
 /* y = [post_leaky](a*([pre_leaky](x) - mu) + beta) [+ skip] */
 int lg_instnorm_leaky_apply(const float* x, const float* stats, const float* skip, float* y, int B, long long L,
                             int pre_leaky, int post_leaky, float alpha, void* stream);

@@ -18,6 +18,9 @@ extern "C" int lg_abi_version(void) { return LG_ABI_VERSION; }
 
 extern "C" int lg_conv_igemm(int mode, int dtype, const float* src, const void* wpack, const float* bias, float* out,
                              int B, int Hm, int Wm, int Cs, int N, int act, int pstride, int ppad, void* stream);
+extern "C" int lg_conv_igemm_stats(int mode, int dtype, const float* src, const void* wpack, const float* bias, float* out,
+                                   int B, int Hm, int Wm, int Cs, int N, int act, int pstride, int ppad, void* spart,
+                                   size_t spart_bytes, int* nparts_out, void* stream);
 extern "C" size_t lg_conv_pack_up_offset(int cb, int cs, int dtype);
 extern "C" size_t lg_conv_pack_raw_offset(int cb, int cs, int dtype);
 extern "C" int lg_n3_s1t_fwd_try(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C,
@@ -61,6 +64,20 @@ static int run_up(const float* small, const void* pack, const float* bias, float
 extern "C" int lg_conv2d_s2_fwd(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws,
                                 int cb, int cs, int dtype, void* stream) {
   return run_down(x, pack, bias, y, B, Hs, Ws, cb, cs, dtype, stream);
+}
+// forward + fused InstanceNorm moment partials (finish with lg_instnorm_stats_finalize when *nparts > 0)
+extern "C" int lg_conv2d_s2_fwd_stats(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws,
+                                      int cb, int cs, int dtype, void* spart, size_t spart_bytes, int* nparts, void* stream) {
+  if (nparts) *nparts = 0;
+  if (cb == 3) return run_down(x, pack, bias, y, B, Hs, Ws, cb, cs, dtype, stream);
+  return lg_conv_igemm_stats(MODE_DOWN, dtype, x, pack, bias, y, B, Hs, Ws, cb, cs, 0, 0, 0, spart, spart_bytes, nparts, stream);
+}
+extern "C" int lg_convT_s2_fwd_stats(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws,
+                                     int cb, int cs, int dtype, void* spart, size_t spart_bytes, int* nparts, void* stream) {
+  if (nparts) *nparts = 0;
+  if (cb == 3) return run_up(x, pack, bias, y, B, Hs, Ws, cb, cs, dtype, stream);
+  return lg_conv_igemm_stats(MODE_UP, dtype, x, up_pack(pack, cb, cs, dtype), bias, y, B, Hs, Ws, cs, cb, 0, 0, 0, spart,
+                             spart_bytes, nparts, stream);
 }
 extern "C" int lg_conv2d_s2_dgrad(const float* dy, const void* pack, float* dx, int B, int Hs, int Ws, int cb, int cs,
                                   int dtype, void* stream) {

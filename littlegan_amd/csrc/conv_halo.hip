@@ -31,6 +31,8 @@ struct HaloParams {
   int TH, TW, NI, tpi_x, tpi;  // tile geometry: tiles per image along x, tiles per image
   int HH, HW, HROWS, nrows;    // halo geometry (per image) and total halo rows
   int dbg;                     // ablation switches for scripts/bench_layer.py (LG_DBG env; 0 in production)
+  double* spart;               // fused InstanceNorm moments: [B][nparts][3] = {count, mean, M2} per block, or null
+  int nparts;
 };
 
 template <typename T> struct DT;
@@ -318,6 +320,56 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
       }
     }
   }
+
+  // ---- fused InstanceNormalization moments of this block's output tile (one sample per block: NI == 1) ----------
+  // {count, mean, M2 about the block mean}, merged per sample with Chan's formula by stats_final_kernel (norm.hip):
+  // the separate pass that re-read the whole conv output for its moments is gone.
+  if (p.spart) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + (wn * NT + j) * 32 + r;
+      if (col < p.N) {
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s += acc[i][j][e] + bv;
+      }
+    }
+    __syncthreads();  // s_out is dead from here on: reuse it as reduction scratch (16-B aligned)
+    double* sred = reinterpret_cast<double*>(s_out);
+    const int ncol = min(BN, p.N - n0);
+    const double cnt = 128.0 * (double)ncol;
+    double red[1] = {(double)s};
+    lg_block_sum_d<1>(red, sred);
+    if (tid == 0) sred[16] = red[0] / cnt;
+    __syncthreads();
+    const float mean = (float)sred[16];
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + (wn * NT + j) * 32 + r;
+      if (col < p.N) {
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { const float d = (acc[i][j][e] + bv) - mean; m2 += d * d; }
+      }
+    }
+    const double meand = sred[16];
+    double red2[1] = {(double)m2};
+    lg_block_sum_d<1>(red2, sred);
+    if (tid == 0) {
+      const int tin = tile_m - img0 * p.tpi;  // tile within the image
+      const int part = (cls * p.tpi + tin) * p.ntn + tile_n;
+      double* o = p.spart + ((long long)img0 * p.nparts + part) * 3;
+      // M2 was taken about the float-rounded mean: shift it to the exact block mean (M2' = M2 - cnt*(mean_f - mean)^2)
+      const double df = (double)mean - meand;
+      o[0] = cnt; o[1] = meand; o[2] = red2[0] - cnt * df * df;
+    }
+  }
 }
 
 constexpr int LDS_BUDGET = 80 * 1024;  // two blocks per CU (160 KiB)
@@ -333,6 +385,7 @@ int launch(HaloParams p, hipStream_t st) {
     if ((NU + min_taps - 2) / (min_taps - 1) > 4) return LG_ERR_UNSUPPORTED;
   }
   p.ntn = p.Npad / BN;
+  p.nparts = (MODE == MODE_UP ? 4 : 1) * p.tpi * p.ntn;
   const int ntm = p.NI == 1 ? p.B * p.tpi : lg_cdiv(p.B, p.NI);
   dim3 grid(ntm * p.ntn, MODE == MODE_UP ? 4 : 1);
   auto kern = conv_halo_kernel<T, MODE, KCH, DBUF, WAVES_M, WAVES_N, MT, NT>;
@@ -379,8 +432,12 @@ inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 extern "C" int lg_npad(int n);
 
 // Returns LG_OK if the halo kernel was launched, LG_ERR_UNSUPPORTED if the caller must use the gather kernel.
+// spart/spart_bytes/nparts_out (optional): if the tiling puts ONE sample per block, the kernel also writes per-block
+// InstanceNorm moments and *nparts_out = partial records per sample (0 = not produced, run the separate stats pass).
 extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const void* wpack, const float* bias, float* out,
-                                int B, int Hm, int Wm, int Cs, int N, int act, void* stream) {
+                                int B, int Hm, int Wm, int Cs, int N, int act, void* spart, size_t spart_bytes,
+                                int* nparts_out, void* stream) {
+  if (nparts_out) *nparts_out = 0;
   if (mode != MODE_DOWN && mode != MODE_UP && mode != MODE_S1T) return LG_ERR_UNSUPPORTED;
   HaloParams p{};
   p.TW = Wm < 16 ? Wm : 16;
@@ -401,6 +458,12 @@ extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const voi
     if (dbg < 0) { const char* e = getenv("LG_DBG"); dbg = e ? atoi(e) : 0; }
     p.dbg = dbg;
   }
+  int nparts = 0;
+  if (spart && nparts_out && p.NI == 1 && act == 0) {
+    const int bn = p.Npad % 128 == 0 ? 128 : (p.Npad % 64 == 0 ? 64 : 32);  // same rule as dispatch_bn2
+    nparts = (mode == MODE_UP ? 4 : 1) * p.tpi * (p.Npad / bn);
+    if ((size_t)B * nparts * 3 * sizeof(double) <= spart_bytes) p.spart = (double*)spart; else nparts = 0;
+  }
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (mode == MODE_DOWN) rc = dispatch<MODE_DOWN>(p, dtype, st);
@@ -408,5 +471,6 @@ extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const voi
   else rc = dispatch<MODE_S1T>(p, dtype, st);
   if (rc != LG_OK) return rc;
   LG_CHECK_LAUNCH("lg_conv_halo");
+  if (nparts_out) *nparts_out = nparts;
   return LG_OK;
 }

@@ -254,6 +254,16 @@ extern "C" int lg_instnorm_leaky_stats(const float* x, float* stats, const float
   return LG_OK;
 }
 
+// stats from moment partials [B][nparts][3] doubles {count, mean, M2} produced by a conv epilogue (conv_halo.hip)
+extern "C" int lg_instnorm_stats_finalize(const void* partials, int nparts, float* stats, const float* gamma,
+                                          const float* beta, int B, void* stream) {
+  LG_CHECK_ARG(partials && stats && gamma && beta && nparts > 0 && B > 0, "lg_instnorm_stats_finalize: bad arguments");
+  hipLaunchKernelGGL(stats_final_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const double*)partials, stats, gamma,
+                     beta, nparts);
+  LG_CHECK_LAUNCH("lg_instnorm_stats_finalize");
+  return LG_OK;
+}
+
 // y = [post_leaky] (a_n * ([pre_leaky](x) - mu_n) + beta) [+ skip]
 extern "C" int lg_instnorm_leaky_apply(const float* x, const float* stats, const float* skip, float* y, int B,
                                        long long L, int pre_leaky, int post_leaky, float alpha, void* stream) {

@@ -128,8 +128,10 @@ class Encoder(_ConvStack):
         saved = []
         B1 = x.shape[0]
         for i, (cb, cs) in enumerate(self.chans, 1):
-            z = ops.conv2d_s2_fwd(x, packs[i - 1], self._w[f"conv{i}.bias"], cs, self.dtype)
-            st = ops.instnorm_stats(z, self._w[f"norm{i}.gamma"], self._w[f"norm{i}.beta"], 0, a)
+            gm, bt = self._w[f"norm{i}.gamma"], self._w[f"norm{i}.beta"]
+            z, st = ops.conv2d_s2_fwd_stats(x, packs[i - 1], self._w[f"conv{i}.bias"], cs, self.dtype, gm, bt)
+            if st is None:  # kernel without the fused-moments epilogue (small maps, 3-channel input)
+                st = ops.instnorm_stats(z, gm, bt, 0, a)
             if tails is None:
                 h = ops.instnorm_apply(z, st, None, 0, 1, a)
                 outs.append(h)
@@ -185,8 +187,10 @@ class Decoder(_ConvStack):
         if add[0] is not None:
             x = x + add[0]  # tiny (init_dim^2 x conv_filter[0]); later skips are fused into the norm-apply pass
         for i, (cb, cs) in enumerate(self.chans, 1):
-            z = ops.convT_s2_fwd(x, packs[i - 1], self._w[f"conv{i}.bias"], cb, self.dtype)
-            st = ops.instnorm_stats(z, self._w[f"norm{i}.gamma"], self._w[f"norm{i}.beta"], 0, a)
+            gm, bt = self._w[f"norm{i}.gamma"], self._w[f"norm{i}.beta"]
+            z, st = ops.convT_s2_fwd_stats(x, packs[i - 1], self._w[f"conv{i}.bias"], cb, self.dtype, gm, bt)
+            if st is None:
+                st = ops.instnorm_stats(z, gm, bt, 0, a)
             skip = add[i] if i < 4 else None
             h = ops.instnorm_apply(z, st, skip, 0, 1, a)
             saved.append((x, z, st))

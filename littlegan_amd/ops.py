@@ -367,3 +367,46 @@ def clip_adam_update(w, g, m, v, state, lr, b1, b2, eps, clip, gscale=1.0):
 
 def adam_advance(state, b1, b2):
     check(_lib.load().lg_adam_advance(_p(state), float(b1), float(b2), _stream()), "lg_adam_advance")
+
+
+# ------------------------------------------------------------------ conv forward with fused InstanceNorm moments
+def _fwd_stats(fn_name, x, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, tag, flops):
+    """Runs the conv; if its kernel produced per-block moment partials, finishes them into the stats record.
+    Returns stats [B, NSTAT] or None (caller then runs instnorm_stats on the output)."""
+    import ctypes
+    lib = _lib.load()
+    ws = workspace(B * 1024 * 24, x.device, "statpart")  # >= B * nparts * 3 doubles for every layer shape (nparts <= 1024)
+    nparts = ctypes.c_int(0)
+    e0 = _pb()
+    check(getattr(lib, fn_name)(_p(x), _p(pack), _p(bias), _p(out), B, Hs, Ws, cb, cs, dtype, _p(ws), ws.numel(),
+                                ctypes.addressof(nparts), _stream()), fn_name)
+    _pe(e0, tag, flops)
+    if nparts.value <= 0:
+        return None
+    stats = torch.empty(B, NSTAT, dtype=torch.float32, device=x.device)
+    check(lib.lg_instnorm_stats_finalize(_p(ws), nparts.value, _p(stats), _p(gamma), _p(beta), B, _stream()),
+          "lg_instnorm_stats_finalize")
+    return stats
+
+
+def conv2d_s2_fwd_stats(x, pack, bias, cs, dtype, gamma, beta):
+    """conv2d_s2_fwd + the InstanceNormalization statistics of its output -> (y, stats or None)."""
+    B, H, W, cb = x.shape
+    _chk(x, name="x")
+    _chk(bias, (cs,), "bias")
+    if H % 2 or W % 2:
+        raise ValueError("conv2d_s2_fwd_stats: H and W must be even")
+    out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.float32, device=x.device)
+    st = _fwd_stats("lg_conv2d_s2_fwd_stats", x, pack, bias, out, B, H // 2, W // 2, cb, cs, dtype, gamma, beta,
+                    "conv_igemm_patch" if cb == 3 else "conv_igemm_down", 50.0 * B * (H // 2) * (W // 2) * cb * cs)
+    return out, st
+
+
+def convT_s2_fwd_stats(x, pack, bias, cb, dtype, gamma, beta):
+    B, Hs, Ws, cs = x.shape
+    _chk(x, name="x")
+    _chk(bias, (cb,), "bias")
+    out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.float32, device=x.device)
+    st = _fwd_stats("lg_convT_s2_fwd_stats", x, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, "conv_igemm_up",
+                    50.0 * B * Hs * Ws * cb * cs)
+    return out, st
