@@ -47,8 +47,14 @@ int lg_conv2d_s2_fwd(const float* x, const void* pack, const float* bias, float*
 /* same + fused InstanceNormalization moment partials of y (instance.py:114-115): when the chosen kernel supports it,
  * *nparts > 0 and spart holds [B][*nparts][3] doubles {count, mean, M2}; finish with lg_instnorm_stats_finalize.
  * *nparts == 0: not produced, use lg_instnorm_leaky_stats. */
-int lg_conv2d_s2_fwd_stats(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws, int cb,
-                           int cs, int dtype, void* spart, size_t spart_bytes, int* nparts, void* stream);
+int lg_conv2d_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y, int B, int Hs,
+                           int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes, int* nparts, void* stream);
+/* *_m16: the activation operands may additionally be given as bf16 mirrors (x16 / dy16, same layout, may be null);
+ * the bf16 MFMA kernels then read those instead of re-reading and re-rounding the fp32 tensors (bit-identical result) */
+int lg_conv2d_s2_dgrad_m16(const float* dy, const void* dy16, const void* pack, float* dx, int B, int Hs, int Ws, int cb,
+                           int cs, int dtype, void* stream);
+int lg_conv2d_s2_wgrad_m16(const float* x, const void* x16, const float* dy, const void* dy16, float* dw, void* workspace,
+                           size_t ws_bytes, int B, int Hs, int Ws, int cb, int cs, int accumulate, int dtype, void* stream);
 /* dx[B,2Hs,2Ws,cb] = conv2d_backprop_input(dy[B,Hs,Ws,cs]) */
 int lg_conv2d_s2_dgrad(const float* dy, const void* pack, float* dx, int B, int Hs, int Ws, int cb, int cs, int dtype,
                        void* stream);
@@ -60,8 +66,12 @@ int lg_conv2d_s2_wgrad(const float* x, const float* dy, float* dw, void* workspa
 /* y[B,2Hs,2Ws,cb] = convT(x[B,Hs,Ws,cs]) + bias   (4-phase sub-pixel implicit GEMM) */
 int lg_convT_s2_fwd(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws, int cb,
                     int cs, int dtype, void* stream);
-int lg_convT_s2_fwd_stats(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws, int cb,
-                          int cs, int dtype, void* spart, size_t spart_bytes, int* nparts, void* stream);
+int lg_convT_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y, int B, int Hs,
+                          int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes, int* nparts, void* stream);
+int lg_convT_s2_dgrad_m16(const float* dy, const void* dy16, const void* pack, float* dx, int B, int Hs, int Ws, int cb,
+                          int cs, int dtype, void* stream);
+int lg_convT_s2_wgrad_m16(const float* x, const void* x16, const float* dy, const void* dy16, float* dw, void* workspace,
+                          size_t ws_bytes, int B, int Hs, int Ws, int cb, int cs, int accumulate, int dtype, void* stream);
 int lg_convT_s2_dgrad(const float* dy, const void* pack, float* dx, int B, int Hs, int Ws, int cb, int cs, int dtype,
                       void* stream);
 int lg_convT_s2_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t ws_bytes, int B, int Hs,
@@ -92,13 +102,14 @@ int lg_instnorm_leaky_stats(const float* x, float* stats, const float* gamma, co
                             size_t ws_bytes, int B, long long L, int pre_leaky, float alpha, void* stream);
 int lg_instnorm_stats_finalize(const void* partials, int nparts, float* stats, const float* gamma, const float* beta,
                                int B, void* stream);
-/* y = [post_leaky](a*([pre_leaky](x) - mu) + beta) [+ skip] */
-int lg_instnorm_leaky_apply(const float* x, const float* stats, const float* skip, float* y, int B, long long L,
-                            int pre_leaky, int post_leaky, float alpha, void* stream);
-/* g = dL/dy (before skip) -> dx ; dgamma/dbeta (device scalars, may be null) */
-int lg_instnorm_leaky_bwd(const float* x, const float* stats, const float* g, float* dx, float* dgamma, float* dbeta,
-                          void* workspace, size_t ws_bytes, int B, long long L, int pre_leaky, int post_leaky,
-                          float alpha, int accumulate, void* stream);
+/* y = [post_leaky](a*([pre_leaky](x) - mu) + beta) [+ skip] ; y16 (may be null): bf16 mirror of y, the MFMA operand
+ * image the bf16 conv / wgrad kernels consume instead of re-reading and re-rounding the fp32 tensor */
+int lg_instnorm_leaky_apply(const float* x, const float* stats, const float* skip, float* y, void* y16, int B,
+                            long long L, int pre_leaky, int post_leaky, float alpha, void* stream);
+/* g = dL/dy (before skip) -> dx (+ bf16 mirror dx16, may be null) ; dgamma/dbeta (device scalars, may be null) */
+int lg_instnorm_leaky_bwd(const float* x, const float* stats, const float* g, float* dx, void* dx16, float* dgamma,
+                          float* dbeta, void* workspace, size_t ws_bytes, int B, long long L, int pre_leaky,
+                          int post_leaky, float alpha, int accumulate, void* stream);
 
 /* ---- tf.compat.v1.layers.Dense  model.py:62-63 (heads, sigmoid), :83, :120 ----------------------- */
 int lg_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, void* stream);

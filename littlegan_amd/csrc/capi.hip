@@ -18,9 +18,12 @@ extern "C" int lg_abi_version(void) { return LG_ABI_VERSION; }
 
 extern "C" int lg_conv_igemm(int mode, int dtype, const float* src, const void* wpack, const float* bias, float* out,
                              int B, int Hm, int Wm, int Cs, int N, int act, int pstride, int ppad, void* stream);
-extern "C" int lg_conv_igemm_stats(int mode, int dtype, const float* src, const void* wpack, const float* bias, float* out,
-                                   int B, int Hm, int Wm, int Cs, int N, int act, int pstride, int ppad, void* spart,
-                                   size_t spart_bytes, int* nparts_out, void* stream);
+extern "C" int lg_conv_igemm_ex(int mode, int dtype, const float* src, const void* src16, const void* wpack,
+                                const float* bias, float* out, int B, int Hm, int Wm, int Cs, int N, int act, int pstride,
+                                int ppad, void* spart, size_t spart_bytes, int* nparts_out, void* stream);
+extern "C" int lg_conv_wgrad_m16(const float* big, const void* big16, const float* small, const void* small16, float* dw,
+                                 void* workspace, size_t ws_bytes, int B, int Hm, int Wm, int cb, int cs, int pstride,
+                                 int ppad, int accumulate, int dtype, void* stream);
 extern "C" size_t lg_conv_pack_up_offset(int cb, int cs, int dtype);
 extern "C" size_t lg_conv_pack_raw_offset(int cb, int cs, int dtype);
 extern "C" int lg_n3_s1t_fwd_try(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C,
@@ -65,19 +68,46 @@ extern "C" int lg_conv2d_s2_fwd(const float* x, const void* pack, const float* b
                                 int cb, int cs, int dtype, void* stream) {
   return run_down(x, pack, bias, y, B, Hs, Ws, cb, cs, dtype, stream);
 }
-// forward + fused InstanceNorm moment partials (finish with lg_instnorm_stats_finalize when *nparts > 0)
-extern "C" int lg_conv2d_s2_fwd_stats(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws,
-                                      int cb, int cs, int dtype, void* spart, size_t spart_bytes, int* nparts, void* stream) {
+// forward + fused InstanceNorm moment partials (finish with lg_instnorm_stats_finalize when *nparts > 0);
+// x16 (optional): bf16 mirror of x for the bf16 MFMA path
+extern "C" int lg_conv2d_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y, int B,
+                                      int Hs, int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes,
+                                      int* nparts, void* stream) {
   if (nparts) *nparts = 0;
   if (cb == 3) return run_down(x, pack, bias, y, B, Hs, Ws, cb, cs, dtype, stream);
-  return lg_conv_igemm_stats(MODE_DOWN, dtype, x, pack, bias, y, B, Hs, Ws, cb, cs, 0, 0, 0, spart, spart_bytes, nparts, stream);
+  return lg_conv_igemm_ex(MODE_DOWN, dtype, x, x16, pack, bias, y, B, Hs, Ws, cb, cs, 0, 0, 0, spart, spart_bytes, nparts,
+                          stream);
 }
-extern "C" int lg_convT_s2_fwd_stats(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws,
-                                     int cb, int cs, int dtype, void* spart, size_t spart_bytes, int* nparts, void* stream) {
+extern "C" int lg_convT_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y, int B,
+                                     int Hs, int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes,
+                                     int* nparts, void* stream) {
   if (nparts) *nparts = 0;
   if (cb == 3) return run_up(x, pack, bias, y, B, Hs, Ws, cb, cs, dtype, stream);
-  return lg_conv_igemm_stats(MODE_UP, dtype, x, up_pack(pack, cb, cs, dtype), bias, y, B, Hs, Ws, cs, cb, 0, 0, 0, spart,
-                             spart_bytes, nparts, stream);
+  return lg_conv_igemm_ex(MODE_UP, dtype, x, x16, up_pack(pack, cb, cs, dtype), bias, y, B, Hs, Ws, cs, cb, 0, 0, 0, spart,
+                          spart_bytes, nparts, stream);
+}
+// data / weight gradients with optional bf16 mirrors of their activation operands
+extern "C" int lg_conv2d_s2_dgrad_m16(const float* dy, const void* dy16, const void* pack, float* dx, int B, int Hs, int Ws,
+                                      int cb, int cs, int dtype, void* stream) {
+  if (cb == 3) return run_up(dy, pack, nullptr, dx, B, Hs, Ws, cb, cs, dtype, stream);
+  return lg_conv_igemm_ex(MODE_UP, dtype, dy, dy16, up_pack(pack, cb, cs, dtype), nullptr, dx, B, Hs, Ws, cs, cb, 0, 0, 0,
+                          nullptr, 0, nullptr, stream);
+}
+extern "C" int lg_convT_s2_dgrad_m16(const float* dy, const void* dy16, const void* pack, float* dx, int B, int Hs, int Ws,
+                                     int cb, int cs, int dtype, void* stream) {
+  if (cb == 3) return run_down(dy, pack, nullptr, dx, B, Hs, Ws, cb, cs, dtype, stream);
+  return lg_conv_igemm_ex(MODE_DOWN, dtype, dy, dy16, pack, nullptr, dx, B, Hs, Ws, cb, cs, 0, 0, 0, nullptr, 0, nullptr,
+                          stream);
+}
+extern "C" int lg_conv2d_s2_wgrad_m16(const float* x, const void* x16, const float* dy, const void* dy16, float* dw,
+                                      void* workspace, size_t ws_bytes, int B, int Hs, int Ws, int cb, int cs,
+                                      int accumulate, int dtype, void* stream) {
+  return lg_conv_wgrad_m16(x, x16, dy, dy16, dw, workspace, ws_bytes, B, Hs, Ws, cb, cs, 2, 1, accumulate, dtype, stream);
+}
+extern "C" int lg_convT_s2_wgrad_m16(const float* x, const void* x16, const float* dy, const void* dy16, float* dw,
+                                     void* workspace, size_t ws_bytes, int B, int Hs, int Ws, int cb, int cs,
+                                     int accumulate, int dtype, void* stream) {
+  return lg_conv_wgrad_m16(dy, dy16, x, x16, dw, workspace, ws_bytes, B, Hs, Ws, cb, cs, 2, 1, accumulate, dtype, stream);
 }
 extern "C" int lg_conv2d_s2_dgrad(const float* dy, const void* pack, float* dx, int B, int Hs, int Ws, int cb, int cs,
                                   int dtype, void* stream) {

@@ -20,6 +20,7 @@ enum { MODE_DOWN = 0, MODE_UP = 1, MODE_S1T = 2 };
 
 struct HaloParams {
   const float* src;
+  const __bf16* src16;         // optional bf16 mirror of src (same NHWC layout); used by the SRC16 instantiations
   const char* wp;
   const float* bias;
   float* out;
@@ -58,14 +59,15 @@ __device__ __forceinline__ void tap_info(int mode, int cls, int t, int& dy, int&
   }
 }
 
-template <typename T, int MODE, int KCH, bool DBUF, int WAVES_M, int WAVES_N, int MT, int NT>
+template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, int WAVES_M, int WAVES_N, int MT, int NT>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
+  static_assert(!SRC16 || (sizeof(T) == 2 && !DBUF), "bf16 source only with bf16 MFMA, single-buffered halo");
   constexpr int ESZ = DT<T>::ESZ;
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
   static_assert(BM == 128, "halo tiles are 128 rows");
   constexpr int ROWB = KCH * 32 + 16;
   constexpr int KC = KCH * 32 / ESZ;
-  constexpr int LPR = KC / 4;        // threads per halo row (fp32 source, float4 each)
+  constexpr int LPR = SRC16 ? KC / 8 : KC / 4;  // threads per halo row (16 B each: 4 fp32 or 8 bf16 channels)
   constexpr int RPP = 256 / LPR;     // halo rows per pass
   constexpr int SS = (MODE == MODE_DOWN) ? 2 : 1;
   constexpr int LO = (MODE == MODE_S1T) ? -2 : -1;
@@ -167,26 +169,44 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
   auto stage_halo = [&](int c0, char* sH) {  // synchronous: up to SU halo rows in flight per thread (one L2/HBM latency
     constexpr int SU = 12;                   // per SU*RPP rows instead of one per 4*RPP)
     for (int hr0 = 0; hr0 < p.nrows; hr0 += SU * RPP) {
-      f32x4 v[SU];
+      if constexpr (SRC16) {  // bf16 mirror: 16 B = 8 channels, straight into the LDS image (no conversion)
+        u32x4 v[SU];
 #pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        const int hr = hr0 + u * RPP + arow;
-        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (hr < p.nrows) {
-          const int o = s_hoff[hr];
-          if (o >= 0) v[u] = *reinterpret_cast<const f32x4*>(p.src + (long long)o * p.Cs + c0 + alc * 4);
+        for (int u = 0; u < SU; ++u) {
+          const int hr = hr0 + u * RPP + arow;
+          v[u] = u32x4{0u, 0u, 0u, 0u};
+          if (hr < p.nrows) {
+            const int o = s_hoff[hr];
+            if (o >= 0) v[u] = *reinterpret_cast<const u32x4*>(p.src16 + (long long)o * p.Cs + c0 + alc * 8);
+          }
         }
-      }
 #pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        const int hr = hr0 + u * RPP + arow;
-        if (hr < p.nrows) {
-          if constexpr (ESZ == 4) {
-            *reinterpret_cast<f32x4*>(sH + hr * ROWB + alc * 16) = v[u];
-          } else {
-            bf16x4 w;
-            w[0] = (__bf16)v[u][0]; w[1] = (__bf16)v[u][1]; w[2] = (__bf16)v[u][2]; w[3] = (__bf16)v[u][3];
-            *reinterpret_cast<bf16x4*>(sH + hr * ROWB + alc * 8) = w;
+        for (int u = 0; u < SU; ++u) {
+          const int hr = hr0 + u * RPP + arow;
+          if (hr < p.nrows) *reinterpret_cast<u32x4*>(sH + hr * ROWB + alc * 16) = v[u];
+        }
+      } else {
+        f32x4 v[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int hr = hr0 + u * RPP + arow;
+          v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (hr < p.nrows) {
+            const int o = s_hoff[hr];
+            if (o >= 0) v[u] = *reinterpret_cast<const f32x4*>(p.src + (long long)o * p.Cs + c0 + alc * 4);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int hr = hr0 + u * RPP + arow;
+          if (hr < p.nrows) {
+            if constexpr (ESZ == 4) {
+              *reinterpret_cast<f32x4*>(sH + hr * ROWB + alc * 16) = v[u];
+            } else {
+              bf16x4 w;
+              w[0] = (__bf16)v[u][0]; w[1] = (__bf16)v[u][1]; w[2] = (__bf16)v[u][2]; w[3] = (__bf16)v[u][3];
+              *reinterpret_cast<bf16x4*>(sH + hr * ROWB + alc * 8) = w;
+            }
           }
         }
       }
@@ -374,13 +394,13 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
 
 constexpr int LDS_BUDGET = 80 * 1024;  // two blocks per CU (160 KiB)
 
-template <typename T, int MODE, int KCH, bool DBUF, int WAVES_M, int WAVES_N, int MT, int NT>
+template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, int WAVES_M, int WAVES_N, int MT, int NT>
 int launch(HaloParams p, hipStream_t st) {
   constexpr int BN = WAVES_N * NT * 32, ROWB = KCH * 32 + 16;
   const size_t lds = ((128 + p.nrows) * 4 + 15) / 16 * 16 + (size_t)p.nrows * ROWB * (DBUF ? 2 : 1);
   if (lds > LDS_BUDGET) return LG_ERR_UNSUPPORTED;
   if (DBUF) {  // the interleaved prefetch must fit its register window: ceil(NU/(ntaps-1)) <= 4 with the fewest taps
-    constexpr int KC = KCH * 32 / DT<T>::ESZ, RPP = 256 / (KC / 4);
+    constexpr int KC = KCH * 32 / DT<T>::ESZ, RPP = 256 / (SRC16 ? KC / 8 : KC / 4);
     const int NU = (p.nrows + RPP - 1) / RPP, min_taps = MODE == MODE_UP ? 4 : 25;
     if ((NU + min_taps - 2) / (min_taps - 1) > 4) return LG_ERR_UNSUPPORTED;
   }
@@ -388,7 +408,7 @@ int launch(HaloParams p, hipStream_t st) {
   p.nparts = (MODE == MODE_UP ? 4 : 1) * p.tpi * p.ntn;
   const int ntm = p.NI == 1 ? p.B * p.tpi : lg_cdiv(p.B, p.NI);
   dim3 grid(ntm * p.ntn, MODE == MODE_UP ? 4 : 1);
-  auto kern = conv_halo_kernel<T, MODE, KCH, DBUF, WAVES_M, WAVES_N, MT, NT>;
+  auto kern = conv_halo_kernel<T, MODE, KCH, DBUF, SRC16, WAVES_M, WAVES_N, MT, NT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET);
@@ -398,17 +418,20 @@ int launch(HaloParams p, hipStream_t st) {
   return LG_OK;
 }
 
-template <typename T, int MODE, int KCH, bool DBUF>
+template <typename T, int MODE, int KCH, bool DBUF, bool SRC16>
 int dispatch_bn2(const HaloParams& p, hipStream_t st) {
-  if (p.Npad % 128 == 0) return launch<T, MODE, KCH, DBUF, 2, 2, 2, 2>(p, st);
-  if (p.Npad % 64 == 0) return launch<T, MODE, KCH, DBUF, 2, 2, 2, 1>(p, st);
-  return launch<T, MODE, KCH, DBUF, 4, 1, 1, 1>(p, st);
+  if (p.Npad % 128 == 0) return launch<T, MODE, KCH, DBUF, SRC16, 2, 2, 2, 2>(p, st);
+  if (p.Npad % 64 == 0) return launch<T, MODE, KCH, DBUF, SRC16, 2, 2, 2, 1>(p, st);
+  return launch<T, MODE, KCH, DBUF, SRC16, 4, 1, 1, 1>(p, st);
 }
 template <typename T, int MODE, int KCH>
 int dispatch_bn(const HaloParams& p, hipStream_t st) {
   int rc = LG_ERR_UNSUPPORTED;
-  if ((p.dbg & 64) && p.Cs / (KCH * 32 / DT<T>::ESZ) > 1) rc = dispatch_bn2<T, MODE, KCH, true>(p, st);  // double-buffered halo: measured slower, opt-in
-  if (rc == LG_ERR_UNSUPPORTED) rc = dispatch_bn2<T, MODE, KCH, false>(p, st);
+  if constexpr (sizeof(T) == 2) {
+    if (p.src16) return dispatch_bn2<T, MODE, KCH, false, true>(p, st);  // bf16 mirror of the source available
+  }
+  if ((p.dbg & 64) && p.Cs / (KCH * 32 / DT<T>::ESZ) > 1) rc = dispatch_bn2<T, MODE, KCH, true, false>(p, st);  // double-buffered halo: measured slower, opt-in
+  if (rc == LG_ERR_UNSUPPORTED) rc = dispatch_bn2<T, MODE, KCH, false, false>(p, st);
   return rc;
 }
 
@@ -434,9 +457,9 @@ extern "C" int lg_npad(int n);
 // Returns LG_OK if the halo kernel was launched, LG_ERR_UNSUPPORTED if the caller must use the gather kernel.
 // spart/spart_bytes/nparts_out (optional): if the tiling puts ONE sample per block, the kernel also writes per-block
 // InstanceNorm moments and *nparts_out = partial records per sample (0 = not produced, run the separate stats pass).
-extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const void* wpack, const float* bias, float* out,
-                                int B, int Hm, int Wm, int Cs, int N, int act, void* spart, size_t spart_bytes,
-                                int* nparts_out, void* stream) {
+extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const void* src16, const void* wpack,
+                                const float* bias, float* out, int B, int Hm, int Wm, int Cs, int N, int act, void* spart,
+                                size_t spart_bytes, int* nparts_out, void* stream) {
   if (nparts_out) *nparts_out = 0;
   if (mode != MODE_DOWN && mode != MODE_UP && mode != MODE_S1T) return LG_ERR_UNSUPPORTED;
   HaloParams p{};
@@ -450,6 +473,7 @@ extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const voi
   const int ss = mode == MODE_DOWN ? 2 : 1, ext = mode == MODE_UP ? 2 : (mode == MODE_DOWN ? 3 : 4);
   p.HH = ss * p.TH + ext; p.HW = ss * p.TW + ext; p.HROWS = p.HH * p.HW; p.nrows = p.NI * p.HROWS;
   p.src = src; p.wp = (const char*)wpack; p.bias = bias; p.out = out;
+  p.src16 = dtype == LG_DT_BF16 ? (const __bf16*)src16 : nullptr;
   p.B = B; p.Cs = Cs; p.Hm = Hm; p.Wm = Wm; p.N = N; p.Npad = lg_npad(N); p.act = act;
   p.Hs = ss * Hm; p.Ws = ss * Wm;
   p.Ho = mode == MODE_UP ? 2 * Hm : Hm; p.Wo = mode == MODE_UP ? 2 * Wm : Wm;

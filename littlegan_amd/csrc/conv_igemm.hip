@@ -326,9 +326,9 @@ int dispatch_dtype(const ConvParams& p, int dtype, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const void* wpack, const float* bias, float* out,
-                                int B, int Hm, int Wm, int Cs, int N, int act, void* spart, size_t spart_bytes,
-                                int* nparts_out, void* stream);
+extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const void* src16, const void* wpack,
+                                const float* bias, float* out, int B, int Hm, int Wm, int Cs, int N, int act, void* spart,
+                                size_t spart_bytes, int* nparts_out, void* stream);
 
 static bool halo_enabled() {
   static int v = -1;
@@ -347,21 +347,22 @@ extern "C" int lg_npad(int n) {
 //   mode 1 UP  : src [B,Hm,Wm,Cs]   -> out [B,2Hm,2Wm,N]
 //   mode 2 S1T : src [B,Hm,Wm,Cs]   -> out [B,Hm,Wm,N]   (+ optional tanh)
 //   mode 3 PATCH: src [B,Hs,Ws,3], stride s, pad p -> out [B,Hm,Wm,N]; wp = [5][Npad][16]
-extern "C" int lg_conv_igemm_stats(int mode, int dtype, const float* src, const void* wpack, const float* bias, float* out,
-                                   int B, int Hm, int Wm, int Cs, int N, int act, int pstride, int ppad, void* spart,
-                                   size_t spart_bytes, int* nparts_out, void* stream);
+extern "C" int lg_conv_igemm_ex(int mode, int dtype, const float* src, const void* src16, const void* wpack,
+                                const float* bias, float* out, int B, int Hm, int Wm, int Cs, int N, int act, int pstride,
+                                int ppad, void* spart, size_t spart_bytes, int* nparts_out, void* stream);
 
 extern "C" int lg_conv_igemm(int mode, int dtype, const float* src, const void* wpack, const float* bias, float* out,
                              int B, int Hm, int Wm, int Cs, int N, int act, int pstride, int ppad, void* stream) {
-  return lg_conv_igemm_stats(mode, dtype, src, wpack, bias, out, B, Hm, Wm, Cs, N, act, pstride, ppad, nullptr, 0, nullptr,
-                             stream);
+  return lg_conv_igemm_ex(mode, dtype, src, nullptr, wpack, bias, out, B, Hm, Wm, Cs, N, act, pstride, ppad, nullptr, 0,
+                          nullptr, stream);
 }
 
-// Same, optionally producing fused InstanceNorm moment partials (see lg_conv_halo_try); *nparts_out == 0 means the
-// chosen kernel did not produce them.
-extern "C" int lg_conv_igemm_stats(int mode, int dtype, const float* src, const void* wpack, const float* bias, float* out,
-                                   int B, int Hm, int Wm, int Cs, int N, int act, int pstride, int ppad, void* spart,
-                                   size_t spart_bytes, int* nparts_out, void* stream) {
+// Same, with (a) an optional bf16 mirror `src16` of the source tensor (used by the bf16 halo kernel instead of
+// re-reading and re-rounding fp32; `src` must still be valid for the fallback kernels) and (b) optional fused
+// InstanceNorm moment partials (see lg_conv_halo_try); *nparts_out == 0 means the chosen kernel did not produce them.
+extern "C" int lg_conv_igemm_ex(int mode, int dtype, const float* src, const void* src16, const void* wpack,
+                                const float* bias, float* out, int B, int Hm, int Wm, int Cs, int N, int act, int pstride,
+                                int ppad, void* spart, size_t spart_bytes, int* nparts_out, void* stream) {
   if (nparts_out) *nparts_out = 0;
   LG_CHECK_ARG(src && wpack && out, "lg_conv_igemm: null pointer");
   LG_CHECK_ARG(B > 0 && Hm > 0 && Wm > 0 && Cs > 0 && N > 0, "lg_conv_igemm: bad shape B=%d Hm=%d Wm=%d Cs=%d N=%d", B, Hm, Wm, Cs, N);
@@ -374,7 +375,8 @@ extern "C" int lg_conv_igemm_stats(int mode, int dtype, const float* src, const 
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (mode != MODE_PATCH && halo_enabled()) {  // LDS halo-tile kernel where the tiling covers the shape
-    rc = lg_conv_halo_try(mode, dtype, src, wpack, bias, out, B, Hm, Wm, Cs, N, act, spart, spart_bytes, nparts_out, stream);
+    rc = lg_conv_halo_try(mode, dtype, src, src16, wpack, bias, out, B, Hm, Wm, Cs, N, act, spart, spart_bytes, nparts_out,
+                          stream);
     if (rc != LG_ERR_UNSUPPORTED) return rc;
   }
   switch (mode) {

@@ -97,8 +97,8 @@ __global__ __launch_bounds__(64) void stats_final_kernel(const double* __restric
 
 __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                     const float* __restrict__ skip, float* __restrict__ y,
-                                                    long long L4, long long total4, int pre_leaky, int post_leaky,
-                                                    float alpha) {
+                                                    __bf16* __restrict__ y16, long long L4, long long total4,
+                                                    int pre_leaky, int post_leaky, float alpha) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
     const int n = (int)(i / L4);
@@ -115,6 +115,11 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ x,
     }
     if (skip) v += *reinterpret_cast<const f32x4*>(skip + i * 4);
     *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    if (y16) {  // bf16 mirror = exactly the MFMA operand the consumers would round to themselves
+      bf16x4 w;
+      w[0] = (__bf16)v[0]; w[1] = (__bf16)v[1]; w[2] = (__bf16)v[2]; w[3] = (__bf16)v[3];
+      *reinterpret_cast<bf16x4*>(y16 + i * 4) = w;
+    }
   }
 }
 
@@ -195,8 +200,8 @@ __global__ __launch_bounds__(256) void bwd_affine_grad_kernel(const double* __re
 
 __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                         const float* __restrict__ stats, const float* __restrict__ bstats,
-                                                        float* __restrict__ dx, long long L4, long long total4,
-                                                        int pre_leaky, int post_leaky, float alpha) {
+                                                        float* __restrict__ dx, __bf16* __restrict__ dx16, long long L4,
+                                                        long long total4, int pre_leaky, int post_leaky, float alpha) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
     const int n = (int)(i / L4);
@@ -218,6 +223,11 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
       o[k] = d;
     }
     *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+    if (dx16) {
+      bf16x4 w;
+      w[0] = (__bf16)o[0]; w[1] = (__bf16)o[1]; w[2] = (__bf16)o[2]; w[3] = (__bf16)o[3];
+      *reinterpret_cast<bf16x4*>(dx16 + i * 4) = w;
+    }
   }
 }
 
@@ -265,20 +275,20 @@ extern "C" int lg_instnorm_stats_finalize(const void* partials, int nparts, floa
 }
 
 // y = [post_leaky] (a_n * ([pre_leaky](x) - mu_n) + beta) [+ skip]
-extern "C" int lg_instnorm_leaky_apply(const float* x, const float* stats, const float* skip, float* y, int B,
+extern "C" int lg_instnorm_leaky_apply(const float* x, const float* stats, const float* skip, float* y, void* y16, int B,
                                        long long L, int pre_leaky, int post_leaky, float alpha, void* stream) {
   LG_CHECK_ARG(x && stats && y, "lg_instnorm_leaky_apply: null pointer");
   LG_CHECK_ARG(B > 0 && L > 0 && L % 4 == 0, "lg_instnorm_leaky_apply: bad shape B=%d L=%lld", B, L);
   const long long total4 = (long long)B * L / 4;
-  hipLaunchKernelGGL(apply_kernel, dim3(ew_blocks(total4)), dim3(256), 0, (hipStream_t)stream, x, stats, skip, y, L / 4,
-                     total4, pre_leaky, post_leaky, alpha);
+  hipLaunchKernelGGL(apply_kernel, dim3(ew_blocks(total4)), dim3(256), 0, (hipStream_t)stream, x, stats, skip, y,
+                     (__bf16*)y16, L / 4, total4, pre_leaky, post_leaky, alpha);
   LG_CHECK_LAUNCH("lg_instnorm_leaky_apply");
   return LG_OK;
 }
 
 // g = dL/d(apply output before skip); writes dx = dL/dx, (accumulates) dgamma, dbeta
-extern "C" int lg_instnorm_leaky_bwd(const float* x, const float* stats, const float* g, float* dx, float* dgamma,
-                                     float* dbeta, void* workspace, size_t ws_bytes, int B, long long L, int pre_leaky,
+extern "C" int lg_instnorm_leaky_bwd(const float* x, const float* stats, const float* g, float* dx, void* dx16,
+                                     float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, int B, long long L, int pre_leaky,
                                      int post_leaky, float alpha, int accumulate, void* stream) {
   LG_CHECK_ARG(x && stats && g && dx && workspace, "lg_instnorm_leaky_bwd: null pointer");
   LG_CHECK_ARG(B > 0 && B <= 65535 && L > 0 && L % 4 == 0, "lg_instnorm_leaky_bwd: bad shape B=%d L=%lld", B, L);
@@ -301,7 +311,7 @@ extern "C" int lg_instnorm_leaky_bwd(const float* x, const float* stats, const f
   }
   const long long total4 = (long long)B * L / 4;
   hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(256), 0, st, x, g, stats, (const float*)bstats, dx,
-                     L / 4, total4, pre_leaky, post_leaky, alpha);
+                     (__bf16*)dx16, L / 4, total4, pre_leaky, post_leaky, alpha);
   LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd(apply)");
   return LG_OK;
 }

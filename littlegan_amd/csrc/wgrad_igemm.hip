@@ -16,6 +16,8 @@ namespace {
 struct WgradParams {
   const float* big;
   const float* small;
+  const __bf16* big16;    // optional bf16 mirrors (SRC16 instantiations): same layouts
+  const __bf16* small16;
   float* slab;
   int B, Hm, Wm, Cb, Cs, M;
   int Cbp;       // slab rows per tap (Cb, or 16 in patch mode)
@@ -24,15 +26,16 @@ struct WgradParams {
   int pstride, ppad;
 };
 
-template <bool BF16, bool PATCH, int WI, int WJ, int MT, int NT>
+template <bool BF16, bool PATCH, bool SRC16, int WI, int WJ, int MT, int NT>
 __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p) {
+  static_assert(!SRC16 || (BF16 && !PATCH), "bf16 sources only for the bf16 MFMA, non-patch kernel");
   constexpr int NTHR = 64 * WI * WJ;
   constexpr int BI = WI * MT * 32, BJ = WJ * NT * 32;
   constexpr int KP = BF16 ? 64 : 32;           // pixels per k tile
   constexpr int ESZ = BF16 ? 2 : 4;
   constexpr int RSA = BI * ESZ + (BF16 ? 16 : 0);   // LDS row strides (bytes)
   constexpr int RSB = BJ * ESZ + (BF16 ? 16 : 0);
-  constexpr int LA = BI / 4, LB = BJ / 4;      // float4 lanes per row
+  constexpr int LA = SRC16 ? BI / 8 : BI / 4, LB = SRC16 ? BJ / 8 : BJ / 4;  // 16-B lanes per row
   static_assert(NTHR % LA == 0 && NTHR % LB == 0, "staging geometry");
   constexpr int RA = NTHR / LA, RB = NTHR / LB;  // rows per pass
   constexpr int PA = KP / RA, PB = KP / RB;
@@ -47,13 +50,16 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
   const int r = lane & 31, h = lane >> 5;
   const int wi = wid / WJ, wj = wid % WJ;
 
-  int bx = blockIdx.x;
+  // logical block order: tap fastest, then channel tile, then pixel split; consecutive logical ids share an XCD
+  // (lg_xcd_remap), so the 25 taps that re-read the same pixel chunk of `big` / `small` run together on one L2
+  // instead of pulling the chunk from HBM 25 times.
+  int bx = lg_xcd_remap(blockIdx.x, gridDim.x);
+  const int t = bx % p.ntaps; bx /= p.ntaps;  // tap
   const int tj = bx % p.ntj; bx /= p.ntj;
   const int ti = bx % p.nti; bx /= p.nti;
-  const int t = bx;  // tap
   const int ky = PATCH ? t : t / 5, kx = PATCH ? 0 : t - (t / 5) * 5;
   const int i0 = ti * BI, j0 = tj * BJ;
-  const int split = blockIdx.y;
+  const int split = bx;
   const int kbeg = split * p.chunk;
   const int kend = min(kbeg + p.chunk, p.M);
   const int nk = (kend - kbeg + KP - 1) / KP;
@@ -87,8 +93,12 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
           }
         } else {
           const int sy = 2 * y + ky - 1, sx = 2 * x + kx - 1;
-          if ((unsigned)sy < (unsigned)Hb && (unsigned)sx < (unsigned)Wb)
-            v = *reinterpret_cast<const f32x4*>(p.big + ((long long)(n * Hb + sy) * Wb + sx) * p.Cb + i0 + alc * 4);
+          if ((unsigned)sy < (unsigned)Hb && (unsigned)sx < (unsigned)Wb) {
+            if constexpr (SRC16)
+              v = __builtin_bit_cast(f32x4, *reinterpret_cast<const u32x4*>(p.big16 + ((long long)(n * Hb + sy) * Wb + sx) * p.Cb + i0 + alc * 8));
+            else
+              v = *reinterpret_cast<const f32x4*>(p.big + ((long long)(n * Hb + sy) * Wb + sx) * p.Cb + i0 + alc * 4);
+          }
         }
       }
       ra[q] = v;
@@ -97,7 +107,10 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
     for (int q = 0; q < PB; ++q) {
       const int m = k0 + q * RB + brow;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < kend) v = *reinterpret_cast<const f32x4*>(p.small + (long long)m * p.Cs + j0 + blc * 4);
+      if (m < kend) {
+        if constexpr (SRC16) v = __builtin_bit_cast(f32x4, *reinterpret_cast<const u32x4*>(p.small16 + (long long)m * p.Cs + j0 + blc * 8));
+        else v = *reinterpret_cast<const f32x4*>(p.small + (long long)m * p.Cs + j0 + blc * 4);
+      }
       rb[q] = v;
     }
   };
@@ -108,7 +121,9 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
       char* d = sA + (q * RA + arow) * RSA;
-      if constexpr (BF16) {
+      if constexpr (SRC16) {
+        *reinterpret_cast<f32x4*>(d + alc * 16) = ra[q];
+      } else if constexpr (BF16) {
         bf16x4 w;
         w[0] = (__bf16)ra[q][0]; w[1] = (__bf16)ra[q][1]; w[2] = (__bf16)ra[q][2]; w[3] = (__bf16)ra[q][3];
         *reinterpret_cast<bf16x4*>(d + alc * 8) = w;
@@ -119,7 +134,9 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
       char* d = sB + (q * RB + brow) * RSB;
-      if constexpr (BF16) {
+      if constexpr (SRC16) {
+        *reinterpret_cast<f32x4*>(d + blc * 16) = rb[q];
+      } else if constexpr (BF16) {
         bf16x4 w;
         w[0] = (__bf16)rb[q][0]; w[1] = (__bf16)rb[q][1]; w[2] = (__bf16)rb[q][2]; w[3] = (__bf16)rb[q][3];
         *reinterpret_cast<bf16x4*>(d + blc * 8) = w;
@@ -265,20 +282,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
-template <bool BF16, bool PATCH, int WI, int WJ, int MT, int NT>
+template <bool BF16, bool PATCH, bool SRC16, int WI, int WJ, int MT, int NT>
 void launch_wgrad(WgradParams p, int nsplit, hipStream_t st) {
   constexpr int BI = WI * MT * 32, BJ = WJ * NT * 32, KP = BF16 ? 64 : 32, ESZ = BF16 ? 2 : 4;
   constexpr int RSA = BI * ESZ + (BF16 ? 16 : 0), RSB = BJ * ESZ + (BF16 ? 16 : 0);
   const size_t lds = 2 * (size_t)KP * (RSA + RSB);
   p.nti = lg_cdiv(p.Cbp, BI);
   p.ntj = lg_cdiv(p.Cs, BJ);
-  auto kern = wgrad_kernel<BF16, PATCH, WI, WJ, MT, NT>;
+  auto kern = wgrad_kernel<BF16, PATCH, SRC16, WI, WJ, MT, NT>;
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid(p.nti * p.ntj * p.ntaps, nsplit);
+  dim3 grid(p.nti * p.ntj * p.ntaps * nsplit);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WI * WJ), lds, st, p);
 }
 
@@ -325,9 +342,21 @@ static size_t wgrad_ws_generic(int B, int Hm, int Wm, int cb, int cs, int dtype)
 // dW[5][5][cb][cs] (+)= big (x) small ; big [B,s*Hm,s*Wm,cb], small [B,Hm,Wm,cs].
 // cb == 3 selects the patch form with source stride `pstride` and pad-before `ppad`
 // (conv1: 2,1 ; stride-1 final layer: 1,2); otherwise stride 2 / pad 1.
+extern "C" int lg_conv_wgrad_m16(const float* big, const void* big16, const float* small, const void* small16, float* dw,
+                                 void* workspace, size_t ws_bytes, int B, int Hm, int Wm, int cb, int cs, int pstride,
+                                 int ppad, int accumulate, int dtype, void* stream);
+
 extern "C" int lg_conv_wgrad(const float* big, const float* small, float* dw, void* workspace, size_t ws_bytes,
                              int B, int Hm, int Wm, int cb, int cs, int pstride, int ppad, int accumulate, int dtype,
                              void* stream) {
+  return lg_conv_wgrad_m16(big, nullptr, small, nullptr, dw, workspace, ws_bytes, B, Hm, Wm, cb, cs, pstride, ppad,
+                           accumulate, dtype, stream);
+}
+
+// big16 / small16 (optional, both or none): bf16 mirrors of the operands, consumed by the bf16 MFMA kernel directly
+extern "C" int lg_conv_wgrad_m16(const float* big, const void* big16, const float* small, const void* small16, float* dw,
+                                 void* workspace, size_t ws_bytes, int B, int Hm, int Wm, int cb, int cs, int pstride,
+                                 int ppad, int accumulate, int dtype, void* stream) {
   LG_CHECK_ARG(big && small && dw && workspace, "lg_conv_wgrad: null pointer");
   LG_CHECK_ARG(B > 0 && Hm > 0 && Wm > 0 && cs % 32 == 0 && (cb == 3 || cb % 32 == 0),
                "lg_conv_wgrad: bad shape B=%d Hm=%d Wm=%d cb=%d cs=%d", B, Hm, Wm, cb, cs);
@@ -341,6 +370,7 @@ extern "C" int lg_conv_wgrad(const float* big, const float* small, float* dw, vo
   const int KP = bf16 ? 64 : 32;
   WgradParams p{};
   p.big = big; p.small = small; p.slab = (float*)workspace;
+  p.big16 = bf16 ? (const __bf16*)big16 : nullptr; p.small16 = bf16 ? (const __bf16*)small16 : nullptr;
   p.B = B; p.Hm = Hm; p.Wm = Wm; p.Cb = cb; p.Cs = cs; p.M = B * Hm * Wm;
   p.Cbp = patch ? 16 : cb; p.ntaps = patch ? 5 : 25; p.pstride = pstride; p.ppad = ppad;
   TileSel ts = pick_tile(patch ? 32 : p.Cbp, cs);
@@ -350,7 +380,8 @@ extern "C" int lg_conv_wgrad(const float* big, const float* small, float* dw, vo
   p.chunk = (lg_cdiv(p.M, ns) + KP - 1) / KP * KP;
   ns = lg_cdiv(p.M, p.chunk);
   hipStream_t st = (hipStream_t)stream;
-#define LG_WG(BF, PT, WI, WJ, MT, NT) launch_wgrad<BF, PT, WI, WJ, MT, NT>(p, ns, st)
+#define LG_WG(BF, PT, WI, WJ, MT, NT) launch_wgrad<BF, PT, false, WI, WJ, MT, NT>(p, ns, st)
+#define LG_WG16(WI, WJ, MT, NT) launch_wgrad<true, false, true, WI, WJ, MT, NT>(p, ns, st)
   if (patch) {
     if (ts.bj == 128) LG_WG(false, true, 1, 2, 1, 2); else if (ts.bj == 64) LG_WG(false, true, 1, 2, 1, 1); else LG_WG(false, true, 1, 1, 1, 1);
   } else if (!bf16) {
@@ -363,6 +394,16 @@ extern "C" int lg_conv_wgrad(const float* big, const float* small, float* dw, vo
     else if (ts.bj == 128) LG_WG(false, false, 1, 2, 1, 2);
     else if (ts.bj == 64) LG_WG(false, false, 1, 2, 1, 1);
     else LG_WG(false, false, 1, 1, 1, 1);
+  } else if (p.big16 && p.small16) {
+    if (ts.bi == 128 && ts.bj == 128) LG_WG16(2, 2, 2, 2);
+    else if (ts.bi == 128 && ts.bj == 64) LG_WG16(2, 2, 2, 1);
+    else if (ts.bi == 128) LG_WG16(4, 1, 1, 1);
+    else if (ts.bi == 64 && ts.bj == 128) LG_WG16(2, 2, 1, 2);
+    else if (ts.bi == 64 && ts.bj == 64) LG_WG16(2, 2, 1, 1);
+    else if (ts.bi == 64) LG_WG16(2, 1, 1, 1);
+    else if (ts.bj == 128) LG_WG16(1, 2, 1, 2);
+    else if (ts.bj == 64) LG_WG16(1, 2, 1, 1);
+    else LG_WG16(1, 1, 1, 1);
   } else {
     if (ts.bi == 128 && ts.bj == 128) LG_WG(true, false, 2, 2, 2, 2);
     else if (ts.bi == 128 && ts.bj == 64) LG_WG(true, false, 2, 2, 2, 1);
@@ -375,6 +416,7 @@ extern "C" int lg_conv_wgrad(const float* big, const float* small, float* dw, vo
     else LG_WG(true, false, 1, 1, 1, 1);
   }
 #undef LG_WG
+#undef LG_WG16
   LG_CHECK_LAUNCH("lg_conv_wgrad");
   const int rows_v = patch ? 15 : cb;
   const long long n_out = (long long)p.ntaps * rows_v * cs;

@@ -127,21 +127,24 @@ class Encoder(_ConvStack):
         outs = []
         saved = []
         B1 = x.shape[0]
+        m16 = self.dtype == DT_BF16  # bf16 MFMA path: keep a bf16 mirror of every conv input (the operand image)
+        x16 = None
         for i, (cb, cs) in enumerate(self.chans, 1):
             gm, bt = self._w[f"norm{i}.gamma"], self._w[f"norm{i}.beta"]
-            z, st = ops.conv2d_s2_fwd_stats(x, packs[i - 1], self._w[f"conv{i}.bias"], cs, self.dtype, gm, bt)
+            z, st = ops.conv2d_s2_fwd_stats(x, packs[i - 1], self._w[f"conv{i}.bias"], cs, self.dtype, gm, bt, x16=x16)
             if st is None:  # kernel without the fused-moments epilogue (small maps, 3-channel input)
                 st = ops.instnorm_stats(z, gm, bt, 0, a)
+            h16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if m16 else None
             if tails is None:
-                h = ops.instnorm_apply(z, st, None, 0, 1, a)
+                h = ops.instnorm_apply(z, st, None, 0, 1, a, out16=h16)
                 outs.append(h)
             else:
                 full = torch.empty((B1 + tails[i - 1].shape[0],) + tuple(z.shape[1:]), dtype=torch.float32, device=z.device)
-                h = ops.instnorm_apply(z, st, None, 0, 1, a, out=full[:B1])
+                h = ops.instnorm_apply(z, st, None, 0, 1, a, out=full[:B1], out16=h16)
                 full[B1:].copy_(tails[i - 1])
                 outs.append(full)
-            saved.append((x, z, st))
-            x = h
+            saved.append((x, z, st, x16))
+            x, x16 = h, h16
         if ctx is not None:
             ctx["enc"] = saved
         return outs
@@ -154,16 +157,18 @@ class Encoder(_ConvStack):
         g_h = g_last
         for i in range(4, 0, -1):
             cb, cs = self.chans[i - 1]
-            x, z, st = ctx["enc"][i - 1]
+            x, z, st, x16 = ctx["enc"][i - 1]
             if rows is not None:
                 x, z, st = x[rows], z[rows], st[rows]
+                x16 = x16[rows] if x16 is not None else None
             dgm = self._g[f"norm{i}.gamma"] if need_wgrad else None
             dbt = self._g[f"norm{i}.beta"] if need_wgrad else None
-            dz = ops.instnorm_bwd(z, st, g_h, dgm, dbt, 0, 1, a)
+            dz16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if (self.dtype == DT_BF16 and cb != 3) else None
+            dz = ops.instnorm_bwd(z, st, g_h, dgm, dbt, 0, 1, a, out16=dz16)
             if need_wgrad:
-                ops.conv2d_s2_wgrad(x, dz, self._g[f"conv{i}.kernel"], False, self.dtype)
+                ops.conv2d_s2_wgrad(x, dz, self._g[f"conv{i}.kernel"], False, self.dtype, x16=x16, dy16=dz16)
                 ops.bias_grad(dz, self._g[f"conv{i}.bias"])
-            g_h = ops.conv2d_s2_dgrad(dz, packs[i - 1], cb, self.dtype) if (i > 1 or need_input_grad) else None
+            g_h = ops.conv2d_s2_dgrad(dz, packs[i - 1], cb, self.dtype, dy16=dz16) if (i > 1 or need_input_grad) else None
         return g_h
 
 
@@ -186,15 +191,18 @@ class Decoder(_ConvStack):
         saved = []
         if add[0] is not None:
             x = x + add[0]  # tiny (init_dim^2 x conv_filter[0]); later skips are fused into the norm-apply pass
+        m16 = self.dtype == DT_BF16
+        x16 = None
         for i, (cb, cs) in enumerate(self.chans, 1):
             gm, bt = self._w[f"norm{i}.gamma"], self._w[f"norm{i}.beta"]
-            z, st = ops.convT_s2_fwd_stats(x, packs[i - 1], self._w[f"conv{i}.bias"], cb, self.dtype, gm, bt)
+            z, st = ops.convT_s2_fwd_stats(x, packs[i - 1], self._w[f"conv{i}.bias"], cb, self.dtype, gm, bt, x16=x16)
             if st is None:
                 st = ops.instnorm_stats(z, gm, bt, 0, a)
             skip = add[i] if i < 4 else None
-            h = ops.instnorm_apply(z, st, skip, 0, 1, a)
-            saved.append((x, z, st))
-            x = h
+            h16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if (m16 and i < 4) else None
+            h = ops.instnorm_apply(z, st, skip, 0, 1, a, out16=h16)
+            saved.append((x, z, st, x16))
+            x, x16 = h, h16
         if ctx is not None:
             ctx["dec"] = saved
         return x
@@ -206,14 +214,15 @@ class Decoder(_ConvStack):
         packs = self.packs()
         for i in range(4, 0, -1):
             cb, cs = self.chans[i - 1]
-            x, z, st = ctx["dec"][i - 1]
+            x, z, st, x16 = ctx["dec"][i - 1]
             dgm = self._g[f"norm{i}.gamma"] if need_wgrad else None
             dbt = self._g[f"norm{i}.beta"] if need_wgrad else None
-            dz = ops.instnorm_bwd(z, st, g_h, dgm, dbt, 0, 1, a)
+            dz16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if self.dtype == DT_BF16 else None
+            dz = ops.instnorm_bwd(z, st, g_h, dgm, dbt, 0, 1, a, out16=dz16)
             if need_wgrad:
-                ops.convT_s2_wgrad(x, dz, self._g[f"conv{i}.kernel"], False, self.dtype)
+                ops.convT_s2_wgrad(x, dz, self._g[f"conv{i}.kernel"], False, self.dtype, x16=x16, dy16=dz16)
                 ops.bias_grad(dz, self._g[f"conv{i}.bias"])
-            g_h = ops.convT_s2_dgrad(dz, packs[i - 1], cs, self.dtype)
+            g_h = ops.convT_s2_dgrad(dz, packs[i - 1], cs, self.dtype, dy16=dz16)
         return g_h
 
 

@@ -110,20 +110,22 @@ def conv2d_s2_fwd(x, pack, bias, cs, dtype, out=None):
     return out
 
 
-def conv2d_s2_dgrad(dy, pack, cb, dtype, out=None):
+def conv2d_s2_dgrad(dy, pack, cb, dtype, out=None, dy16=None):
     B, Hs, Ws, cs = dy.shape
     _chk(dy, name="dy")
+    if dy16 is not None:
+        _chk16(dy16, dy, "dy16")
     if out is None:
         out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.float32, device=dy.device)
     _chk(out, (B, 2 * Hs, 2 * Ws, cb), "out")
     e0 = _pb()
-    check(_lib.load().lg_conv2d_s2_dgrad(_p(dy), _p(pack), _p(out), B, Hs, Ws, cb, cs, dtype, _stream()),
-          "lg_conv2d_s2_dgrad")
+    check(_lib.load().lg_conv2d_s2_dgrad_m16(_p(dy), _p(dy16), _p(pack), _p(out), B, Hs, Ws, cb, cs, dtype, _stream()),
+          "lg_conv2d_s2_dgrad_m16")
     _pe(e0, "conv_igemm_up_n3" if cb == 3 else "conv_igemm_up", 50.0 * B * Hs * Ws * cb * cs)
     return out
 
 
-def _wgrad(fn_name, big, small, dw, accumulate, dtype, swap):
+def _wgrad(fn_name, big, small, dw, accumulate, dtype, swap, big16=None, small16=None):
     lib = _lib.load()
     B, Hs, Ws, cs = small.shape
     cb = big.shape[3]
@@ -132,17 +134,22 @@ def _wgrad(fn_name, big, small, dw, accumulate, dtype, swap):
     _chk(dw, (5, 5, cb, cs), "dw")
     nbytes = int(lib.lg_wgrad_workspace_bytes(B, Hs, Ws, cb, cs, dtype))
     ws = workspace(nbytes, big.device, "wgrad")
-    a, b = (small, big) if swap else (big, small)
+    if big16 is None or small16 is None:
+        big16 = small16 = None  # the bf16-source kernel needs both mirrors
+    else:
+        _chk16(big16, big, "big16")
+        _chk16(small16, small, "small16")
+    (a, a16), (b, b16) = ((small, small16), (big, big16)) if swap else ((big, big16), (small, small16))
     e0 = _pb()
-    check(getattr(lib, fn_name)(_p(a), _p(b), _p(dw), _p(ws), ws.numel(), B, Hs, Ws, cb, cs, int(accumulate), dtype,
-                                _stream()), fn_name)
+    check(getattr(lib, fn_name)(_p(a), _p(a16), _p(b), _p(b16), _p(dw), _p(ws), ws.numel(), B, Hs, Ws, cb, cs,
+                                int(accumulate), dtype, _stream()), fn_name)
     _pe(e0, "wgrad_patch" if cb == 3 else "wgrad_igemm", 50.0 * B * Hs * Ws * cb * cs)
     return dw
 
 
-def conv2d_s2_wgrad(x, dy, dw, accumulate, dtype):
-    """dw[5,5,cb,cs] (+)= wgrad(x [B,2Hs,2Ws,cb], dy [B,Hs,Ws,cs])"""
-    return _wgrad("lg_conv2d_s2_wgrad", x, dy, dw, accumulate, dtype, swap=False)
+def conv2d_s2_wgrad(x, dy, dw, accumulate, dtype, x16=None, dy16=None):
+    """dw[5,5,cb,cs] (+)= wgrad(x [B,2Hs,2Ws,cb], dy [B,Hs,Ws,cs]); x16/dy16: optional bf16 mirrors"""
+    return _wgrad("lg_conv2d_s2_wgrad_m16", x, dy, dw, accumulate, dtype, swap=False, big16=x16, small16=dy16)
 
 
 def convT_s2_fwd(x, pack, bias, cb, dtype, out=None):
@@ -160,22 +167,24 @@ def convT_s2_fwd(x, pack, bias, cb, dtype, out=None):
     return out
 
 
-def convT_s2_dgrad(dy, pack, cs, dtype, out=None):
+def convT_s2_dgrad(dy, pack, cs, dtype, out=None, dy16=None):
     B, H, W, cb = dy.shape
     _chk(dy, name="dy")
+    if dy16 is not None:
+        _chk16(dy16, dy, "dy16")
     if out is None:
         out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.float32, device=dy.device)
     _chk(out, (B, H // 2, W // 2, cs), "out")
     e0 = _pb()
-    check(_lib.load().lg_convT_s2_dgrad(_p(dy), _p(pack), _p(out), B, H // 2, W // 2, cb, cs, dtype, _stream()),
-          "lg_convT_s2_dgrad")
+    check(_lib.load().lg_convT_s2_dgrad_m16(_p(dy), _p(dy16), _p(pack), _p(out), B, H // 2, W // 2, cb, cs, dtype, _stream()),
+          "lg_convT_s2_dgrad_m16")
     _pe(e0, "conv_igemm_down", 50.0 * B * (H // 2) * (W // 2) * cb * cs)
     return out
 
 
-def convT_s2_wgrad(x, dy, dw, accumulate, dtype):
-    """dw[5,5,cb,cs] (+)= wgrad(x [B,Hs,Ws,cs], dy [B,2Hs,2Ws,cb])"""
-    return _wgrad("lg_convT_s2_wgrad", dy, x, dw, accumulate, dtype, swap=True)
+def convT_s2_wgrad(x, dy, dw, accumulate, dtype, x16=None, dy16=None):
+    """dw[5,5,cb,cs] (+)= wgrad(x [B,Hs,Ws,cs], dy [B,2Hs,2Ws,cb]); x16/dy16: optional bf16 mirrors"""
+    return _wgrad("lg_convT_s2_wgrad_m16", dy, x, dw, accumulate, dtype, swap=True, big16=dy16, small16=x16)
 
 
 def convT_s1_tanh_fwd(x, pack, bias, cb, dtype, out=None):
@@ -237,7 +246,13 @@ def instnorm_stats(x, gamma, beta, pre_leaky, alpha, stats=None):
     return stats
 
 
-def instnorm_apply(x, stats, skip, pre_leaky, post_leaky, alpha, out=None):
+def _chk16(t, like, name):
+    if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.numel() == like.numel()):
+        raise ValueError(f"{name}: need a contiguous bf16 CUDA tensor with {like.numel()} elements")
+    return t
+
+
+def instnorm_apply(x, stats, skip, pre_leaky, post_leaky, alpha, out=None, out16=None):
     B = x.shape[0]
     Ln = x.numel() // B
     _chk(x, name="x")
@@ -249,12 +264,14 @@ def instnorm_apply(x, stats, skip, pre_leaky, post_leaky, alpha, out=None):
     if out is None:
         out = torch.empty_like(x)
     _chk(out, x.shape, "out")
-    check(_lib.load().lg_instnorm_leaky_apply(_p(x), _p(stats), _p(skip), _p(out), B, Ln, int(pre_leaky),
+    if out16 is not None:
+        _chk16(out16, out, "out16")
+    check(_lib.load().lg_instnorm_leaky_apply(_p(x), _p(stats), _p(skip), _p(out), _p(out16), B, Ln, int(pre_leaky),
                                               int(post_leaky), float(alpha), _stream()), "lg_instnorm_leaky_apply")
     return out
 
 
-def instnorm_bwd(x, stats, g, dgamma, dbeta, pre_leaky, post_leaky, alpha, accumulate=False, out=None):
+def instnorm_bwd(x, stats, g, dgamma, dbeta, pre_leaky, post_leaky, alpha, accumulate=False, out=None, out16=None):
     B = x.shape[0]
     Ln = x.numel() // B
     _chk(x, name="x")
@@ -267,7 +284,9 @@ def instnorm_bwd(x, stats, g, dgamma, dbeta, pre_leaky, post_leaky, alpha, accum
     _chk(out, x.shape, "out")
     lib = _lib.load()
     ws = workspace(int(lib.lg_instnorm_workspace_bytes(B, Ln)), x.device, "small")
-    check(lib.lg_instnorm_leaky_bwd(_p(x), _p(stats), _p(g), _p(out), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), B, Ln,
+    if out16 is not None:
+        _chk16(out16, out, "out16")
+    check(lib.lg_instnorm_leaky_bwd(_p(x), _p(stats), _p(g), _p(out), _p(out16), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), B, Ln,
                                     int(pre_leaky), int(post_leaky), float(alpha), int(accumulate), _stream()),
           "lg_instnorm_leaky_bwd")
     return out
@@ -370,7 +389,7 @@ def adam_advance(state, b1, b2):
 
 
 # ------------------------------------------------------------------ conv forward with fused InstanceNorm moments
-def _fwd_stats(fn_name, x, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, tag, flops):
+def _fwd_stats(fn_name, x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, tag, flops):
     """Runs the conv; if its kernel produced per-block moment partials, finishes them into the stats record.
     Returns stats [B, NSTAT] or None (caller then runs instnorm_stats on the output)."""
     import ctypes
@@ -378,7 +397,9 @@ def _fwd_stats(fn_name, x, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, bet
     ws = workspace(B * 1024 * 24, x.device, "statpart")  # >= B * nparts * 3 doubles for every layer shape (nparts <= 1024)
     nparts = ctypes.c_int(0)
     e0 = _pb()
-    check(getattr(lib, fn_name)(_p(x), _p(pack), _p(bias), _p(out), B, Hs, Ws, cb, cs, dtype, _p(ws), ws.numel(),
+    if x16 is not None:
+        _chk16(x16, x, "x16")
+    check(getattr(lib, fn_name)(_p(x), _p(x16), _p(pack), _p(bias), _p(out), B, Hs, Ws, cb, cs, dtype, _p(ws), ws.numel(),
                                 ctypes.addressof(nparts), _stream()), fn_name)
     _pe(e0, tag, flops)
     if nparts.value <= 0:
@@ -389,7 +410,7 @@ def _fwd_stats(fn_name, x, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, bet
     return stats
 
 
-def conv2d_s2_fwd_stats(x, pack, bias, cs, dtype, gamma, beta):
+def conv2d_s2_fwd_stats(x, pack, bias, cs, dtype, gamma, beta, x16=None):
     """conv2d_s2_fwd + the InstanceNormalization statistics of its output -> (y, stats or None)."""
     B, H, W, cb = x.shape
     _chk(x, name="x")
@@ -397,16 +418,16 @@ def conv2d_s2_fwd_stats(x, pack, bias, cs, dtype, gamma, beta):
     if H % 2 or W % 2:
         raise ValueError("conv2d_s2_fwd_stats: H and W must be even")
     out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.float32, device=x.device)
-    st = _fwd_stats("lg_conv2d_s2_fwd_stats", x, pack, bias, out, B, H // 2, W // 2, cb, cs, dtype, gamma, beta,
+    st = _fwd_stats("lg_conv2d_s2_fwd_stats", x, x16, pack, bias, out, B, H // 2, W // 2, cb, cs, dtype, gamma, beta,
                     "conv_igemm_patch" if cb == 3 else "conv_igemm_down", 50.0 * B * (H // 2) * (W // 2) * cb * cs)
     return out, st
 
 
-def convT_s2_fwd_stats(x, pack, bias, cb, dtype, gamma, beta):
+def convT_s2_fwd_stats(x, pack, bias, cb, dtype, gamma, beta, x16=None):
     B, Hs, Ws, cs = x.shape
     _chk(x, name="x")
     _chk(bias, (cb,), "bias")
     out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.float32, device=x.device)
-    st = _fwd_stats("lg_convT_s2_fwd_stats", x, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, "conv_igemm_up",
+    st = _fwd_stats("lg_convT_s2_fwd_stats", x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, "conv_igemm_up",
                     50.0 * B * Hs * Ws * cb * cs)
     return out, st

@@ -258,3 +258,55 @@ def test_halo_tile_kernel_matches_oracle(ops, case, dtype):
         got = ops.convT_s1_tanh_fwd(dev(x), ops.conv_pack(dev(w), N, Cs, dtype), dev(b), N, dtype)
         exp = np.tanh(O.conv2d_transpose(x, w, b, 1))
     assert rel(got, exp) < TOL[dtype]
+
+
+@pytest.mark.parametrize("case", [("up", 2, 16, 16, 64, 128), ("down", 2, 16, 16, 64, 128), ("up", 2, 32, 32, 64, 32),
+                                  ("down", 3, 8, 8, 32, 64)])
+def test_bf16_mirror_operands_are_bit_identical(ops, case):
+    """The bf16 mirrors written by the norm kernels are exactly the MFMA operand images the conv / wgrad kernels
+    would round to themselves, so feeding them must not change a single bit of the result."""
+    mode, B, Hm, Wm, Cs, N = case
+    rng = np.random.default_rng(17)
+    if mode == "up":   # convT fwd / its wgrad: small = x [B,Hm,Wm,Cs], big = dy [B,2Hm,2Wm,N]
+        x, w, dy = r32(rng, B, Hm, Wm, Cs), r32(rng, 5, 5, N, Cs, scale=0.1), r32(rng, B, 2 * Hm, 2 * Wm, N)
+        xd, dyd, pack = dev(x), dev(dy), ops.conv_pack(dev(w), N, Cs, 1)
+        x16, dy16 = xd.to(torch.bfloat16), dyd.to(torch.bfloat16)
+        b = torch.zeros(N, device="cuda")
+        y0 = ops.convT_s2_fwd(xd, pack, b, N, 1)
+        gm, bt = torch.ones(1, device="cuda"), torch.zeros(1, device="cuda")
+        y1, st = ops.convT_s2_fwd_stats(xd, pack, b, N, 1, gm, bt, x16=x16)
+        dx0, dx1 = ops.convT_s2_dgrad(dyd, pack, Cs, 1), ops.convT_s2_dgrad(dyd, pack, Cs, 1, dy16=dy16)
+        dw0, dw1 = torch.empty(5, 5, N, Cs, device="cuda"), torch.empty(5, 5, N, Cs, device="cuda")
+        ops.convT_s2_wgrad(xd, dyd, dw0, False, 1)
+        ops.convT_s2_wgrad(xd, dyd, dw1, False, 1, x16=x16, dy16=dy16)
+        zz = y1
+    else:              # conv fwd: big = x [B,2Hm,2Wm,Cs], small = dy [B,Hm,Wm,N]
+        x, w, dy = r32(rng, B, 2 * Hm, 2 * Wm, Cs), r32(rng, 5, 5, Cs, N, scale=0.1), r32(rng, B, Hm, Wm, N)
+        xd, dyd, pack = dev(x), dev(dy), ops.conv_pack(dev(w), Cs, N, 1)
+        x16, dy16 = xd.to(torch.bfloat16), dyd.to(torch.bfloat16)
+        b = torch.zeros(N, device="cuda")
+        y0 = ops.conv2d_s2_fwd(xd, pack, b, N, 1)
+        gm, bt = torch.ones(1, device="cuda"), torch.zeros(1, device="cuda")
+        y1, st = ops.conv2d_s2_fwd_stats(xd, pack, b, N, 1, gm, bt, x16=x16)
+        dx0, dx1 = ops.conv2d_s2_dgrad(dyd, pack, Cs, 1), ops.conv2d_s2_dgrad(dyd, pack, Cs, 1, dy16=dy16)
+        dw0, dw1 = torch.empty(5, 5, Cs, N, device="cuda"), torch.empty(5, 5, Cs, N, device="cuda")
+        ops.conv2d_s2_wgrad(xd, dyd, dw0, False, 1)
+        ops.conv2d_s2_wgrad(xd, dyd, dw1, False, 1, x16=x16, dy16=dy16)
+        zz = y1
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1) and torch.equal(dw0, dw1)
+    if st is not None:  # fused moments == moments of the produced tensor
+        zf = zz.double().reshape(B, -1)
+        assert rel(st[:, 0], zf.mean(1).cpu().numpy()) < 1e-6 and rel(st[:, 1], zf.std(1, unbiased=False).cpu().numpy()) < 1e-6
+
+
+def test_norm_kernels_write_bf16_mirrors(ops):
+    rng = np.random.default_rng(3)
+    x, g = dev(r32(rng, 3, 8, 8, 32)), dev(r32(rng, 3, 8, 8, 32))
+    gm, bt = dev(np.array([1.2])), dev(np.array([0.1]))
+    st = ops.instnorm_stats(x, gm, bt, 0, 0.3)
+    y16 = torch.empty(x.shape, dtype=torch.bfloat16, device="cuda")
+    y = ops.instnorm_apply(x, st, None, 0, 1, 0.3, out16=y16)
+    assert torch.equal(y16, y.to(torch.bfloat16))
+    d16 = torch.empty(x.shape, dtype=torch.bfloat16, device="cuda")
+    d = ops.instnorm_bwd(x, st, g, None, None, 0, 1, 0.3, out16=d16)
+    assert torch.equal(d16, d.to(torch.bfloat16))
