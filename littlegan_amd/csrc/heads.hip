@@ -47,9 +47,20 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
       if (b0 + b < B && k0 + k4 < K) v = *reinterpret_cast<const f32x4*>(x + (long long)(b0 + b) * K + k0 + k4);
       *reinterpret_cast<f32x4*>(xs + b * KCH + k4) = v;
     }
-    if (vec_ok) {
+    if (vec_ok) {  // 256*c/4 <= 2560 float4: all (up to 10 per thread) in flight before the first LDS store
       const f32x4* g = reinterpret_cast<const f32x4*>(wc + (long long)k0 * c);
-      for (int i = threadIdx.x; i < kn * c / 4; i += 256) reinterpret_cast<f32x4*>(swc)[i] = g[i];
+      const int n4 = kn * c / 4;
+      f32x4 v[10];
+#pragma unroll
+      for (int u = 0; u < 10; ++u) {
+        const int i = u * 256 + threadIdx.x;
+        v[u] = i < n4 ? g[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 10; ++u) {
+        const int i = u * 256 + threadIdx.x;
+        if (i < n4) reinterpret_cast<f32x4*>(swc)[i] = v[u];
+      }
     } else {
       for (int i = threadIdx.x; i < kn * c; i += 256) swc[i] = wc[(long long)k0 * c + i];
     }

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void n3_slab_reduce_kernel(const float* __rest
   }
 }
 
-inline int wgrad_blocks(int ntiles) { return ntiles < 256 ? ntiles : 256; }
+inline int wgrad_blocks(int ntiles) { return ntiles < 512 ? ntiles : 512; }
 
 }  // namespace
 
