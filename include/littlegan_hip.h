@@ -51,8 +51,9 @@ int lg_conv2d_s2_fwd_stats(const float* x, const void* x16, const void* pack, co
                            int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes, int* nparts, void* stream);
 /* *_m16: the activation operands may additionally be given as bf16 mirrors (x16 / dy16, same layout, may be null);
  * the bf16 MFMA kernels then read those instead of re-reading and re-rounding the fp32 tensors (bit-identical result) */
-int lg_conv2d_s2_dgrad_m16(const float* dy, const void* dy16, const void* pack, float* dx, int B, int Hs, int Ws, int cb,
-                           int cs, int dtype, void* stream);
+/* dx16 (may be null): write the data gradient as bf16 there INSTEAD of fp32 to dx (dx may then be null) */
+int lg_conv2d_s2_dgrad_m16(const float* dy, const void* dy16, const void* pack, float* dx, void* dx16, int B, int Hs, int Ws,
+                           int cb, int cs, int dtype, void* stream);
 int lg_conv2d_s2_wgrad_m16(const float* x, const void* x16, const float* dy, const void* dy16, float* dw, void* workspace,
                            size_t ws_bytes, int B, int Hs, int Ws, int cb, int cs, int accumulate, int dtype, void* stream);
 /* dx[B,2Hs,2Ws,cb] = conv2d_backprop_input(dy[B,Hs,Ws,cs]) */
@@ -68,8 +69,8 @@ int lg_convT_s2_fwd(const float* x, const void* pack, const float* bias, float* 
                     int cs, int dtype, void* stream);
 int lg_convT_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y, int B, int Hs,
                           int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes, int* nparts, void* stream);
-int lg_convT_s2_dgrad_m16(const float* dy, const void* dy16, const void* pack, float* dx, int B, int Hs, int Ws, int cb,
-                          int cs, int dtype, void* stream);
+int lg_convT_s2_dgrad_m16(const float* dy, const void* dy16, const void* pack, float* dx, void* dx16, int B, int Hs, int Ws,
+                          int cb, int cs, int dtype, void* stream);
 int lg_convT_s2_wgrad_m16(const float* x, const void* x16, const float* dy, const void* dy16, float* dw, void* workspace,
                           size_t ws_bytes, int B, int Hs, int Ws, int cb, int cs, int accumulate, int dtype, void* stream);
 int lg_convT_s2_dgrad(const float* dy, const void* pack, float* dx, int B, int Hs, int Ws, int cb, int cs, int dtype,
@@ -106,10 +107,11 @@ int lg_instnorm_stats_finalize(const void* partials, int nparts, float* stats, c
  * image the bf16 conv / wgrad kernels consume instead of re-reading and re-rounding the fp32 tensor */
 int lg_instnorm_leaky_apply(const float* x, const float* stats, const float* skip, float* y, void* y16, int B,
                             long long L, int pre_leaky, int post_leaky, float alpha, void* stream);
-/* g = dL/dy (before skip) -> dx (+ bf16 mirror dx16, may be null) ; dgamma/dbeta (device scalars, may be null) */
-int lg_instnorm_leaky_bwd(const float* x, const float* stats, const float* g, float* dx, void* dx16, float* dgamma,
-                          float* dbeta, void* workspace, size_t ws_bytes, int B, long long L, int pre_leaky,
-                          int post_leaky, float alpha, int accumulate, void* stream);
+/* g = dL/dy (before skip), fp32 or (g_is_bf16) bf16 -> dx fp32 and/or its bf16 mirror dx16 (at least one non-null);
+ * dgamma/dbeta (device scalars, may be null) */
+int lg_instnorm_leaky_bwd(const float* x, const float* stats, const void* g, int g_is_bf16, float* dx, void* dx16,
+                          float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, int B, long long L,
+                          int pre_leaky, int post_leaky, float alpha, int accumulate, void* stream);
 
 /* ---- tf.compat.v1.layers.Dense  model.py:62-63 (heads, sigmoid), :83, :120 ----------------------- */
 int lg_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, void* stream);

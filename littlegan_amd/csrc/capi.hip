@@ -19,8 +19,8 @@ extern "C" int lg_abi_version(void) { return LG_ABI_VERSION; }
 extern "C" int lg_conv_igemm(int mode, int dtype, const float* src, const void* wpack, const float* bias, float* out,
                              int B, int Hm, int Wm, int Cs, int N, int act, int pstride, int ppad, void* stream);
 extern "C" int lg_conv_igemm_ex(int mode, int dtype, const float* src, const void* src16, const void* wpack,
-                                const float* bias, float* out, int B, int Hm, int Wm, int Cs, int N, int act, int pstride,
-                                int ppad, void* spart, size_t spart_bytes, int* nparts_out, void* stream);
+                                const float* bias, float* out, void* out16, int B, int Hm, int Wm, int Cs, int N, int act,
+                                int pstride, int ppad, void* spart, size_t spart_bytes, int* nparts_out, void* stream);
 extern "C" int lg_conv_wgrad_m16(const float* big, const void* big16, const float* small, const void* small16, float* dw,
                                  void* workspace, size_t ws_bytes, int B, int Hm, int Wm, int cb, int cs, int pstride,
                                  int ppad, int accumulate, int dtype, void* stream);
@@ -75,28 +75,34 @@ extern "C" int lg_conv2d_s2_fwd_stats(const float* x, const void* x16, const voi
                                       int* nparts, void* stream) {
   if (nparts) *nparts = 0;
   if (cb == 3) return run_down(x, pack, bias, y, B, Hs, Ws, cb, cs, dtype, stream);
-  return lg_conv_igemm_ex(MODE_DOWN, dtype, x, x16, pack, bias, y, B, Hs, Ws, cb, cs, 0, 0, 0, spart, spart_bytes, nparts,
-                          stream);
+  return lg_conv_igemm_ex(MODE_DOWN, dtype, x, x16, pack, bias, y, nullptr, B, Hs, Ws, cb, cs, 0, 0, 0, spart, spart_bytes,
+                          nparts, stream);
 }
 extern "C" int lg_convT_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y, int B,
                                      int Hs, int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes,
                                      int* nparts, void* stream) {
   if (nparts) *nparts = 0;
   if (cb == 3) return run_up(x, pack, bias, y, B, Hs, Ws, cb, cs, dtype, stream);
-  return lg_conv_igemm_ex(MODE_UP, dtype, x, x16, up_pack(pack, cb, cs, dtype), bias, y, B, Hs, Ws, cs, cb, 0, 0, 0, spart,
-                          spart_bytes, nparts, stream);
+  return lg_conv_igemm_ex(MODE_UP, dtype, x, x16, up_pack(pack, cb, cs, dtype), bias, y, nullptr, B, Hs, Ws, cs, cb, 0, 0, 0,
+                          spart, spart_bytes, nparts, stream);
 }
 // data / weight gradients with optional bf16 mirrors of their activation operands
-extern "C" int lg_conv2d_s2_dgrad_m16(const float* dy, const void* dy16, const void* pack, float* dx, int B, int Hs, int Ws,
-                                      int cb, int cs, int dtype, void* stream) {
-  if (cb == 3) return run_up(dy, pack, nullptr, dx, B, Hs, Ws, cb, cs, dtype, stream);
-  return lg_conv_igemm_ex(MODE_UP, dtype, dy, dy16, up_pack(pack, cb, cs, dtype), nullptr, dx, B, Hs, Ws, cs, cb, 0, 0, 0,
-                          nullptr, 0, nullptr, stream);
+extern "C" int lg_conv2d_s2_dgrad_m16(const float* dy, const void* dy16, const void* pack, float* dx, void* dx16, int B,
+                                      int Hs, int Ws, int cb, int cs, int dtype, void* stream) {
+  if (cb == 3) {
+    LG_CHECK_ARG(dx && !dx16, "lg_conv2d_s2_dgrad_m16: the 3-channel image gradient is fp32 only");
+    return run_up(dy, pack, nullptr, dx, B, Hs, Ws, cb, cs, dtype, stream);
+  }
+  return lg_conv_igemm_ex(MODE_UP, dtype, dy, dy16, up_pack(pack, cb, cs, dtype), nullptr, dx, dx16, B, Hs, Ws, cs, cb, 0, 0,
+                          0, nullptr, 0, nullptr, stream);
 }
-extern "C" int lg_convT_s2_dgrad_m16(const float* dy, const void* dy16, const void* pack, float* dx, int B, int Hs, int Ws,
-                                     int cb, int cs, int dtype, void* stream) {
-  if (cb == 3) return run_down(dy, pack, nullptr, dx, B, Hs, Ws, cb, cs, dtype, stream);
-  return lg_conv_igemm_ex(MODE_DOWN, dtype, dy, dy16, pack, nullptr, dx, B, Hs, Ws, cb, cs, 0, 0, 0, nullptr, 0, nullptr,
+extern "C" int lg_convT_s2_dgrad_m16(const float* dy, const void* dy16, const void* pack, float* dx, void* dx16, int B,
+                                     int Hs, int Ws, int cb, int cs, int dtype, void* stream) {
+  if (cb == 3) {
+    LG_CHECK_ARG(dx && !dx16, "lg_convT_s2_dgrad_m16: 3-channel layers are fp32 only");
+    return run_down(dy, pack, nullptr, dx, B, Hs, Ws, cb, cs, dtype, stream);
+  }
+  return lg_conv_igemm_ex(MODE_DOWN, dtype, dy, dy16, pack, nullptr, dx, dx16, B, Hs, Ws, cb, cs, 0, 0, 0, nullptr, 0, nullptr,
                           stream);
 }
 extern "C" int lg_conv2d_s2_wgrad_m16(const float* x, const void* x16, const float* dy, const void* dy16, float* dw,

@@ -24,6 +24,7 @@ struct HaloParams {
   const char* wp;
   const float* bias;
   float* out;
+  __bf16* out16;  // if non-null the result is written as bf16 HERE instead of fp32 to `out`
   int B, Hs, Ws, Cs;
   int Hm, Wm;
   int Ho, Wo, N, Npad;
@@ -335,7 +336,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
         if (cok && o >= 0) {
           float v = acc[i][j][e] + bv;
           if (p.act == 1) v = tanhf(v);
-          p.out[(long long)o * p.N + col] = v;
+          if (p.out16) p.out16[(long long)o * p.N + col] = (__bf16)v;
+          else p.out[(long long)o * p.N + col] = v;
         }
       }
     }
@@ -458,7 +460,7 @@ extern "C" int lg_npad(int n);
 // spart/spart_bytes/nparts_out (optional): if the tiling puts ONE sample per block, the kernel also writes per-block
 // InstanceNorm moments and *nparts_out = partial records per sample (0 = not produced, run the separate stats pass).
 extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const void* src16, const void* wpack,
-                                const float* bias, float* out, int B, int Hm, int Wm, int Cs, int N, int act, void* spart,
+                                const float* bias, float* out, void* out16, int B, int Hm, int Wm, int Cs, int N, int act, void* spart,
                                 size_t spart_bytes, int* nparts_out, void* stream) {
   if (nparts_out) *nparts_out = 0;
   if (mode != MODE_DOWN && mode != MODE_UP && mode != MODE_S1T) return LG_ERR_UNSUPPORTED;
@@ -472,7 +474,7 @@ extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const voi
   p.tpi_x = Wm / p.TW; p.tpi = p.tpi_x * (Hm / p.TH);
   const int ss = mode == MODE_DOWN ? 2 : 1, ext = mode == MODE_UP ? 2 : (mode == MODE_DOWN ? 3 : 4);
   p.HH = ss * p.TH + ext; p.HW = ss * p.TW + ext; p.HROWS = p.HH * p.HW; p.nrows = p.NI * p.HROWS;
-  p.src = src; p.wp = (const char*)wpack; p.bias = bias; p.out = out;
+  p.src = src; p.wp = (const char*)wpack; p.bias = bias; p.out = out; p.out16 = (__bf16*)out16;
   p.src16 = dtype == LG_DT_BF16 ? (const __bf16*)src16 : nullptr;
   p.B = B; p.Cs = Cs; p.Hm = Hm; p.Wm = Wm; p.N = N; p.Npad = lg_npad(N); p.act = act;
   p.Hs = ss * Hm; p.Ws = ss * Wm;

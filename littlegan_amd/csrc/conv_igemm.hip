@@ -29,6 +29,7 @@ struct ConvParams {
   const char* wp;
   const float* bias;
   float* out;
+  __bf16* out16;  // if non-null the result is written as bf16 HERE instead of fp32 to `out`
   int B, Hs, Ws, Cs;  // source tensor [B,Hs,Ws,Cs]
   int Hm, Wm, M;      // M grid (rows = B*Hm*Wm)
   int Ho, Wo, N, Npad;
@@ -280,7 +281,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         if (cok && o >= 0) {
           float v = acc[i][j][e] + bv;
           if (p.act == 1) v = tanhf(v);
-          p.out[(long long)o * p.N + col] = v;
+          if (p.out16) p.out16[(long long)o * p.N + col] = (__bf16)v;
+          else p.out[(long long)o * p.N + col] = v;
         }
       }
     }
@@ -327,7 +329,7 @@ int dispatch_dtype(const ConvParams& p, int dtype, hipStream_t st) {
 }  // namespace
 
 extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const void* src16, const void* wpack,
-                                const float* bias, float* out, int B, int Hm, int Wm, int Cs, int N, int act, void* spart,
+                                const float* bias, float* out, void* out16, int B, int Hm, int Wm, int Cs, int N, int act, void* spart,
                                 size_t spart_bytes, int* nparts_out, void* stream);
 
 static bool halo_enabled() {
@@ -348,35 +350,36 @@ extern "C" int lg_npad(int n) {
 //   mode 2 S1T : src [B,Hm,Wm,Cs]   -> out [B,Hm,Wm,N]   (+ optional tanh)
 //   mode 3 PATCH: src [B,Hs,Ws,3], stride s, pad p -> out [B,Hm,Wm,N]; wp = [5][Npad][16]
 extern "C" int lg_conv_igemm_ex(int mode, int dtype, const float* src, const void* src16, const void* wpack,
-                                const float* bias, float* out, int B, int Hm, int Wm, int Cs, int N, int act, int pstride,
-                                int ppad, void* spart, size_t spart_bytes, int* nparts_out, void* stream);
+                                const float* bias, float* out, void* out16, int B, int Hm, int Wm, int Cs, int N, int act,
+                                int pstride, int ppad, void* spart, size_t spart_bytes, int* nparts_out, void* stream);
 
 extern "C" int lg_conv_igemm(int mode, int dtype, const float* src, const void* wpack, const float* bias, float* out,
                              int B, int Hm, int Wm, int Cs, int N, int act, int pstride, int ppad, void* stream) {
-  return lg_conv_igemm_ex(mode, dtype, src, nullptr, wpack, bias, out, B, Hm, Wm, Cs, N, act, pstride, ppad, nullptr, 0,
-                          nullptr, stream);
+  return lg_conv_igemm_ex(mode, dtype, src, nullptr, wpack, bias, out, nullptr, B, Hm, Wm, Cs, N, act, pstride, ppad,
+                          nullptr, 0, nullptr, stream);
 }
 
 // Same, with (a) an optional bf16 mirror `src16` of the source tensor (used by the bf16 halo kernel instead of
 // re-reading and re-rounding fp32; `src` must still be valid for the fallback kernels) and (b) optional fused
 // InstanceNorm moment partials (see lg_conv_halo_try); *nparts_out == 0 means the chosen kernel did not produce them.
+// out16 (optional): write the result as bf16 there instead of fp32 to `out` (data gradients of the bf16 path).
 extern "C" int lg_conv_igemm_ex(int mode, int dtype, const float* src, const void* src16, const void* wpack,
-                                const float* bias, float* out, int B, int Hm, int Wm, int Cs, int N, int act, int pstride,
-                                int ppad, void* spart, size_t spart_bytes, int* nparts_out, void* stream) {
+                                const float* bias, float* out, void* out16, int B, int Hm, int Wm, int Cs, int N, int act,
+                                int pstride, int ppad, void* spart, size_t spart_bytes, int* nparts_out, void* stream) {
   if (nparts_out) *nparts_out = 0;
-  LG_CHECK_ARG(src && wpack && out, "lg_conv_igemm: null pointer");
+  LG_CHECK_ARG(src && wpack && (out || out16), "lg_conv_igemm: null pointer");
   LG_CHECK_ARG(B > 0 && Hm > 0 && Wm > 0 && Cs > 0 && N > 0, "lg_conv_igemm: bad shape B=%d Hm=%d Wm=%d Cs=%d N=%d", B, Hm, Wm, Cs, N);
   LG_CHECK_ARG(dtype == LG_DT_F32 || dtype == LG_DT_BF16, "lg_conv_igemm: bad dtype %d", dtype);
   LG_CHECK_ARG((long long)B * Hm * Wm < (1ll << 31) / 4, "lg_conv_igemm: M grid too large");
   ConvParams p{};
-  p.src = src; p.wp = (const char*)wpack; p.bias = bias; p.out = out;
+  p.src = src; p.wp = (const char*)wpack; p.bias = bias; p.out = out; p.out16 = (__bf16*)out16;
   p.B = B; p.Cs = Cs; p.Hm = Hm; p.Wm = Wm; p.M = B * Hm * Wm; p.N = N; p.Npad = lg_npad(N); p.act = act;
   p.pstride = pstride; p.ppad = ppad;
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (mode != MODE_PATCH && halo_enabled()) {  // LDS halo-tile kernel where the tiling covers the shape
-    rc = lg_conv_halo_try(mode, dtype, src, src16, wpack, bias, out, B, Hm, Wm, Cs, N, act, spart, spart_bytes, nparts_out,
-                          stream);
+    rc = lg_conv_halo_try(mode, dtype, src, src16, wpack, bias, out, out16, B, Hm, Wm, Cs, N, act, spart, spart_bytes,
+                          nparts_out, stream);
     if (rc != LG_ERR_UNSUPPORTED) return rc;
   }
   switch (mode) {

@@ -123,8 +123,16 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ x,
   }
 }
 
+__device__ __forceinline__ f32x4 load_g4(const void* g, long long i4, int g16) {  // 4 gradient values, fp32 or bf16 storage
+  if (g16) {
+    const bf16x4 w = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(g) + i4);
+    return f32x4{(float)w[0], (float)w[1], (float)w[2], (float)w[3]};
+  }
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g) + i4);
+}
+
 // partial[n][chunk] = {sum dz, sum dz*c} (doubles)
-__global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restrict__ x, const void* __restrict__ g, int g16,
                                                           const float* __restrict__ stats, double* __restrict__ partial,
                                                           long long L, int nchunk, int pre_leaky, int post_leaky,
                                                           float alpha) {
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restric
     const int e = (q * 256 + threadIdx.x) * 4;
     if (e < lim) {
       const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + e);
-      const f32x4 gv = *reinterpret_cast<const f32x4*>(g + base + e);
+      const f32x4 gv = load_g4(g, base + e, g16);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float xx = xv[k];
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(256) void bwd_affine_grad_kernel(const double* __re
   }
 }
 
-__global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict__ x, const void* __restrict__ g, int g16,
                                                         const float* __restrict__ stats, const float* __restrict__ bstats,
                                                         float* __restrict__ dx, __bf16* __restrict__ dx16, long long L4,
                                                         long long total4, int pre_leaky, int post_leaky, float alpha) {
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
     const float mu = sp[0], a = sp[2], b = sp[3], mul = sp[4];
     const float m1 = bstats[n * 4], m2 = bstats[n * 4 + 1], m1l = bstats[n * 4 + 2], m2l = bstats[n * 4 + 3];
     const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
-    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
+    const f32x4 gv = load_g4(g, i * 4, g16);
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
       if (pre_leaky) d = (xv[k] > 0.f) ? d : alpha * d;
       o[k] = d;
     }
-    *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+    if (dx) *reinterpret_cast<f32x4*>(dx + i * 4) = o;
     if (dx16) {
       bf16x4 w;
       w[0] = (__bf16)o[0]; w[1] = (__bf16)o[1]; w[2] = (__bf16)o[2]; w[3] = (__bf16)o[3];
@@ -287,10 +295,11 @@ extern "C" int lg_instnorm_leaky_apply(const float* x, const float* stats, const
 }
 
 // g = dL/d(apply output before skip); writes dx = dL/dx, (accumulates) dgamma, dbeta
-extern "C" int lg_instnorm_leaky_bwd(const float* x, const float* stats, const float* g, float* dx, void* dx16,
+// g: dL/dy as fp32, or as bf16 when g_is_bf16; dx and dx16: fp32 result and/or its bf16 mirror (at least one)
+extern "C" int lg_instnorm_leaky_bwd(const float* x, const float* stats, const void* g, int g_is_bf16, float* dx, void* dx16,
                                      float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, int B, long long L, int pre_leaky,
                                      int post_leaky, float alpha, int accumulate, void* stream) {
-  LG_CHECK_ARG(x && stats && g && dx && workspace, "lg_instnorm_leaky_bwd: null pointer");
+  LG_CHECK_ARG(x && stats && g && (dx || dx16) && workspace, "lg_instnorm_leaky_bwd: null pointer");
   LG_CHECK_ARG(B > 0 && B <= 65535 && L > 0 && L % 4 == 0, "lg_instnorm_leaky_bwd: bad shape B=%d L=%lld", B, L);
   LG_CHECK_ARG(ws_bytes >= lg_instnorm_workspace_bytes(B, L), "lg_instnorm_leaky_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
@@ -299,7 +308,7 @@ extern "C" int lg_instnorm_leaky_bwd(const float* x, const float* stats, const f
   double* partial = (double*)ws;
   float* bstats = (float*)(ws + part_bytes(B, L));
   double* gsum = (double*)(ws + part_bytes(B, L) + bst_bytes(B));
-  hipLaunchKernelGGL(bwd_partial_kernel, dim3(nc, B), dim3(256), 0, st, x, g, stats, partial, L, nc, pre_leaky,
+  hipLaunchKernelGGL(bwd_partial_kernel, dim3(nc, B), dim3(256), 0, st, x, g, g_is_bf16, stats, partial, L, nc, pre_leaky,
                      post_leaky, alpha);
   LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd(partial)");
   hipLaunchKernelGGL(bwd_final_kernel, dim3(B), dim3(64), 0, st, (const double*)partial, stats, bstats, gsum, L, nc);
@@ -310,7 +319,7 @@ extern "C" int lg_instnorm_leaky_bwd(const float* x, const float* stats, const f
     LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd(affine)");
   }
   const long long total4 = (long long)B * L / 4;
-  hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(256), 0, st, x, g, stats, (const float*)bstats, dx,
+  hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(256), 0, st, x, g, g_is_bf16, stats, (const float*)bstats, dx,
                      (__bf16*)dx16, L / 4, total4, pre_leaky, post_leaky, alpha);
   LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd(apply)");
   return LG_OK;

@@ -168,7 +168,10 @@ class Encoder(_ConvStack):
             if need_wgrad:
                 ops.conv2d_s2_wgrad(x, dz, self._g[f"conv{i}.kernel"], False, self.dtype, x16=x16, dy16=dz16)
                 ops.bias_grad(dz, self._g[f"conv{i}.bias"])
-            g_h = ops.conv2d_s2_dgrad(dz, packs[i - 1], cb, self.dtype, dy16=dz16) if (i > 1 or need_input_grad) else None
+            # the gradient handed to the next (lower) level's norm backward stays bf16 in the bf16 path; the image
+            # gradient of level 1 is fp32 (consumed by the loss / tanh backward)
+            g_h = (ops.conv2d_s2_dgrad(dz, packs[i - 1], cb, self.dtype, dy16=dz16, out_bf16=(self.dtype == DT_BF16 and i > 1))
+                   if (i > 1 or need_input_grad) else None)
         return g_h
 
 
@@ -222,7 +225,7 @@ class Decoder(_ConvStack):
             if need_wgrad:
                 ops.convT_s2_wgrad(x, dz, self._g[f"conv{i}.kernel"], False, self.dtype, x16=x16, dy16=dz16)
                 ops.bias_grad(dz, self._g[f"conv{i}.bias"])
-            g_h = ops.convT_s2_dgrad(dz, packs[i - 1], cs, self.dtype, dy16=dz16)
+            g_h = ops.convT_s2_dgrad(dz, packs[i - 1], cs, self.dtype, dy16=dz16, out_bf16=(self.dtype == DT_BF16 and i > 1))
         return g_h
 
 

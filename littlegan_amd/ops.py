@@ -110,16 +110,22 @@ def conv2d_s2_fwd(x, pack, bias, cs, dtype, out=None):
     return out
 
 
-def conv2d_s2_dgrad(dy, pack, cb, dtype, out=None, dy16=None):
+def conv2d_s2_dgrad(dy, pack, cb, dtype, out=None, dy16=None, out_bf16=False):
+    """dx [B,2Hs,2Ws,cb]; out_bf16: return the gradient as a bf16 tensor (no fp32 copy is written)"""
     B, Hs, Ws, cs = dy.shape
     _chk(dy, name="dy")
     if dy16 is not None:
         _chk16(dy16, dy, "dy16")
-    if out is None:
-        out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.float32, device=dy.device)
-    _chk(out, (B, 2 * Hs, 2 * Ws, cb), "out")
+    if out_bf16:
+        out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.bfloat16, device=dy.device)
+        o32, o16 = None, out
+    else:
+        if out is None:
+            out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.float32, device=dy.device)
+        _chk(out, (B, 2 * Hs, 2 * Ws, cb), "out")
+        o32, o16 = out, None
     e0 = _pb()
-    check(_lib.load().lg_conv2d_s2_dgrad_m16(_p(dy), _p(dy16), _p(pack), _p(out), B, Hs, Ws, cb, cs, dtype, _stream()),
+    check(_lib.load().lg_conv2d_s2_dgrad_m16(_p(dy), _p(dy16), _p(pack), _p(o32), _p(o16), B, Hs, Ws, cb, cs, dtype, _stream()),
           "lg_conv2d_s2_dgrad_m16")
     _pe(e0, "conv_igemm_up_n3" if cb == 3 else "conv_igemm_up", 50.0 * B * Hs * Ws * cb * cs)
     return out
@@ -167,17 +173,22 @@ def convT_s2_fwd(x, pack, bias, cb, dtype, out=None):
     return out
 
 
-def convT_s2_dgrad(dy, pack, cs, dtype, out=None, dy16=None):
+def convT_s2_dgrad(dy, pack, cs, dtype, out=None, dy16=None, out_bf16=False):
     B, H, W, cb = dy.shape
     _chk(dy, name="dy")
     if dy16 is not None:
         _chk16(dy16, dy, "dy16")
-    if out is None:
-        out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.float32, device=dy.device)
-    _chk(out, (B, H // 2, W // 2, cs), "out")
+    if out_bf16:
+        out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.bfloat16, device=dy.device)
+        o32, o16 = None, out
+    else:
+        if out is None:
+            out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.float32, device=dy.device)
+        _chk(out, (B, H // 2, W // 2, cs), "out")
+        o32, o16 = out, None
     e0 = _pb()
-    check(_lib.load().lg_convT_s2_dgrad_m16(_p(dy), _p(dy16), _p(pack), _p(out), B, H // 2, W // 2, cb, cs, dtype, _stream()),
-          "lg_convT_s2_dgrad_m16")
+    check(_lib.load().lg_convT_s2_dgrad_m16(_p(dy), _p(dy16), _p(pack), _p(o32), _p(o16), B, H // 2, W // 2, cb, cs, dtype,
+                                            _stream()), "lg_convT_s2_dgrad_m16")
     _pe(e0, "conv_igemm_down", 50.0 * B * (H // 2) * (W // 2) * cb * cs)
     return out
 
@@ -271,24 +282,36 @@ def instnorm_apply(x, stats, skip, pre_leaky, post_leaky, alpha, out=None, out16
     return out
 
 
-def instnorm_bwd(x, stats, g, dgamma, dbeta, pre_leaky, post_leaky, alpha, accumulate=False, out=None, out16=None):
+def instnorm_bwd(x, stats, g, dgamma, dbeta, pre_leaky, post_leaky, alpha, accumulate=False, out=None, out16=None,
+                 want_f32=True):
+    """g may be fp32 or bf16 (as written by a bf16 data-gradient conv).  Returns the fp32 dx (or None if want_f32 is
+    False, in which case only the bf16 mirror out16 is written)."""
     B = x.shape[0]
     Ln = x.numel() // B
     _chk(x, name="x")
-    _chk(g, name="g")
-    if g.numel() != x.numel():
-        raise ValueError("instnorm_bwd: g has a different size")
+    g16 = g.dtype == torch.bfloat16
+    if g16:
+        _chk16(g, x, "g")
+    else:
+        _chk(g, name="g")
+        if g.numel() != x.numel():
+            raise ValueError("instnorm_bwd: g has a different size")
     _chk(stats, (B, NSTAT), "stats")
-    if out is None:
-        out = torch.empty_like(x)
-    _chk(out, x.shape, "out")
+    if want_f32:
+        if out is None:
+            out = torch.empty_like(x)
+        _chk(out, x.shape, "out")
+    else:
+        if out16 is None:
+            raise ValueError("instnorm_bwd: want_f32=False needs out16")
+        out = None
+    if out16 is not None:
+        _chk16(out16, x, "out16")
     lib = _lib.load()
     ws = workspace(int(lib.lg_instnorm_workspace_bytes(B, Ln)), x.device, "small")
-    if out16 is not None:
-        _chk16(out16, out, "out16")
-    check(lib.lg_instnorm_leaky_bwd(_p(x), _p(stats), _p(g), _p(out), _p(out16), _p(dgamma), _p(dbeta), _p(ws), ws.numel(), B, Ln,
-                                    int(pre_leaky), int(post_leaky), float(alpha), int(accumulate), _stream()),
-          "lg_instnorm_leaky_bwd")
+    check(lib.lg_instnorm_leaky_bwd(_p(x), _p(stats), _p(g), int(g16), _p(out), _p(out16), _p(dgamma), _p(dbeta), _p(ws),
+                                    ws.numel(), B, Ln, int(pre_leaky), int(post_leaky), float(alpha), int(accumulate),
+                                    _stream()), "lg_instnorm_leaky_bwd")
     return out
 
 
