@@ -94,6 +94,12 @@ size_t lg_bias_grad_workspace_bytes(long long M, int C);
 int lg_bias_grad(const float* dy, float* db, void* workspace, size_t ws_bytes, long long M, int C, int accumulate,
                  void* stream);
 
+int lg_bias_grad_m16(const float* dy, const void* dy16, float* db, void* workspace, size_t ws_bytes, long long M, int C,
+                     int accumulate, void* stream);
+/* 1 if the LDS halo-tile kernel covers the shape (mode 0 = conv-form "down", 1 = convT-form "up"); the fp32 copy of a
+ * tensor that has a bf16 mirror is then never read by the conv that consumes it */
+int lg_conv_halo_supported(int mode, int dtype, int B, int Hm, int Wm, int Cs, int N);
+
 /* ---- InstanceNormalization(axis=None) + LeakyReLU + skip add  instance.py:105-128, model.py:24,46-50 */
 size_t lg_instnorm_workspace_bytes(int B, long long L);
 /* stats[B][8] = {mu_hi, sigma, a, beta, mu_lo, 0,0,0} of (pre_leaky ? leaky(x) : x); a = gamma/(sigma+1e-3);

@@ -39,6 +39,8 @@ SIGNATURES = {
     "lg_convT_s1_bwd_workspace_bytes": (Z, [I, I, I, I, I, I]),
     "lg_bias_grad_workspace_bytes": (Z, [L, I]),
     "lg_bias_grad": (I, [P, P, P, Z, L, I, I, P]),
+    "lg_bias_grad_m16": (I, [P, P, P, P, Z, L, I, I, P]),
+    "lg_conv_halo_supported": (I, [I, I, I, I, I, I, I]),
     "lg_instnorm_workspace_bytes": (Z, [I, L]),
     "lg_instnorm_stats_stride": (I, []),
     "lg_instnorm_leaky_stats": (I, [P, P, P, P, P, Z, I, L, I, F, P]),

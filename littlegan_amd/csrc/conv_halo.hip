@@ -35,6 +35,7 @@ struct HaloParams {
   int dbg;                     // ablation switches for scripts/bench_layer.py (LG_DBG env; 0 in production)
   double* spart;               // fused InstanceNorm moments: [B][nparts][3] = {count, mean, M2} per block, or null
   int nparts;
+  int dry;                     // 1: only answer whether this kernel covers the shape (no launch)
 };
 
 template <typename T> struct DT;
@@ -416,6 +417,7 @@ int launch(HaloParams p, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET);
     attr_set = true;
   }
+  if (p.dry) return LG_OK;
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   return LG_OK;
 }
@@ -475,6 +477,7 @@ extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const voi
   const int ss = mode == MODE_DOWN ? 2 : 1, ext = mode == MODE_UP ? 2 : (mode == MODE_DOWN ? 3 : 4);
   p.HH = ss * p.TH + ext; p.HW = ss * p.TW + ext; p.HROWS = p.HH * p.HW; p.nrows = p.NI * p.HROWS;
   p.src = src; p.wp = (const char*)wpack; p.bias = bias; p.out = out; p.out16 = (__bf16*)out16;
+  p.dry = (!out && !out16) ? 1 : 0;
   p.src16 = dtype == LG_DT_BF16 ? (const __bf16*)src16 : nullptr;
   p.B = B; p.Cs = Cs; p.Hm = Hm; p.Wm = Wm; p.N = N; p.Npad = lg_npad(N); p.act = act;
   p.Hs = ss * Hm; p.Ws = ss * Wm;
@@ -496,7 +499,15 @@ extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const voi
   else if (mode == MODE_UP) rc = dispatch<MODE_UP>(p, dtype, st);
   else rc = dispatch<MODE_S1T>(p, dtype, st);
   if (rc != LG_OK) return rc;
+  if (p.dry) return LG_OK;
   LG_CHECK_LAUNCH("lg_conv_halo");
   if (nparts_out) *nparts_out = nparts;
   return LG_OK;
+}
+
+// 1 if the halo kernel covers this shape (then the bf16 mirror alone is enough as its source), else 0
+extern "C" int lg_conv_halo_supported(int mode, int dtype, int B, int Hm, int Wm, int Cs, int N) {
+  static const int dummy = 0;
+  return lg_conv_halo_try(mode, dtype, nullptr, dtype == LG_DT_BF16 ? &dummy : nullptr, &dummy, nullptr, nullptr, nullptr, B,
+                          Hm, Wm, Cs, N, 0, nullptr, 0, nullptr, nullptr) == LG_OK ? 1 : 0;
 }

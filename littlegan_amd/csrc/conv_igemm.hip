@@ -367,7 +367,7 @@ extern "C" int lg_conv_igemm_ex(int mode, int dtype, const float* src, const voi
                                 const float* bias, float* out, void* out16, int B, int Hm, int Wm, int Cs, int N, int act,
                                 int pstride, int ppad, void* spart, size_t spart_bytes, int* nparts_out, void* stream) {
   if (nparts_out) *nparts_out = 0;
-  LG_CHECK_ARG(src && wpack && (out || out16), "lg_conv_igemm: null pointer");
+  LG_CHECK_ARG((src || src16) && wpack && (out || out16), "lg_conv_igemm: null pointer");
   LG_CHECK_ARG(B > 0 && Hm > 0 && Wm > 0 && Cs > 0 && N > 0, "lg_conv_igemm: bad shape B=%d Hm=%d Wm=%d Cs=%d N=%d", B, Hm, Wm, Cs, N);
   LG_CHECK_ARG(dtype == LG_DT_F32 || dtype == LG_DT_BF16, "lg_conv_igemm: bad dtype %d", dtype);
   LG_CHECK_ARG((long long)B * Hm * Wm < (1ll << 31) / 4, "lg_conv_igemm: M grid too large");
@@ -382,6 +382,7 @@ extern "C" int lg_conv_igemm_ex(int mode, int dtype, const float* src, const voi
                           nparts_out, stream);
     if (rc != LG_ERR_UNSUPPORTED) return rc;
   }
+  LG_CHECK_ARG(src, "lg_conv_igemm: this shape needs the per-tap gather kernel, which reads the fp32 source (got only bf16)");
   switch (mode) {
     case MODE_DOWN:
       p.Hs = 2 * Hm; p.Ws = 2 * Wm; p.Ho = Hm; p.Wo = Wm;

@@ -257,8 +257,8 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
 }
 
 // column sums of a [M][C] matrix: partial[blk][C]
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ partial,
-                                                     long long M, int C, long long rows_per_blk) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, const __bf16* __restrict__ x16,
+                                                     float* __restrict__ partial, long long M, int C, long long rows_per_blk) {
   const int c4 = C / 4;                 // C % 4 == 0
   const int tpc = 256 / c4 > 0 ? 256 / c4 : 1;  // threads per column-quad along rows
   const long long r0 = (long long)blockIdx.x * rows_per_blk;
@@ -270,7 +270,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     const int nr = c4 >= 256 ? 1 : tpc;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (cq < c4 && rr < nr)
-      for (long long m = r0 + rr; m < r1; m += nr) s += *reinterpret_cast<const f32x4*>(x + m * C + cq * 4);
+      for (long long m = r0 + rr; m < r1; m += nr) {
+        if (x16) {
+          const bf16x4 w = *reinterpret_cast<const bf16x4*>(x16 + m * C + cq * 4);
+          s += f32x4{(float)w[0], (float)w[1], (float)w[2], (float)w[3]};
+        } else {
+          s += *reinterpret_cast<const f32x4*>(x + m * C + cq * 4);
+        }
+      }
     sred[threadIdx.x] = s;
     __syncthreads();
     if (rr == 0 && cq < c4) {
@@ -357,7 +364,8 @@ extern "C" int lg_conv_wgrad(const float* big, const float* small, float* dw, vo
 extern "C" int lg_conv_wgrad_m16(const float* big, const void* big16, const float* small, const void* small16, float* dw,
                                  void* workspace, size_t ws_bytes, int B, int Hm, int Wm, int cb, int cs, int pstride,
                                  int ppad, int accumulate, int dtype, void* stream) {
-  LG_CHECK_ARG(big && small && dw && workspace, "lg_conv_wgrad: null pointer");
+  LG_CHECK_ARG(dw && workspace && ((big && small) || (big16 && small16 && dtype == LG_DT_BF16 && cb != 3)),
+               "lg_conv_wgrad: null pointer (fp32 operands may be omitted only when both bf16 mirrors are given)");
   LG_CHECK_ARG(B > 0 && Hm > 0 && Wm > 0 && cs % 32 == 0 && (cb == 3 || cb % 32 == 0),
                "lg_conv_wgrad: bad shape B=%d Hm=%d Wm=%d cb=%d cs=%d", B, Hm, Wm, cb, cs);
   LG_CHECK_ARG(ws_bytes >= lg_wgrad_workspace_bytes(B, Hm, Wm, cb, cs, dtype), "lg_conv_wgrad: workspace too small");
@@ -433,10 +441,17 @@ extern "C" size_t lg_bias_grad_workspace_bytes(long long M, int C) {
   return (size_t)nb * C * sizeof(float);
 }
 
+extern "C" int lg_bias_grad_m16(const float* dy, const void* dy16, float* db, void* workspace, size_t ws_bytes, long long M,
+                                int C, int accumulate, void* stream);
 // db[C] (+)= column sums of dy[M][C]
 extern "C" int lg_bias_grad(const float* dy, float* db, void* workspace, size_t ws_bytes, long long M, int C,
                             int accumulate, void* stream) {
-  LG_CHECK_ARG(dy && db && workspace, "lg_bias_grad: null pointer");
+  return lg_bias_grad_m16(dy, nullptr, db, workspace, ws_bytes, M, C, accumulate, stream);
+}
+// same; if dy16 (bf16 [M][C]) is given it is read instead of dy (dy may then be null)
+extern "C" int lg_bias_grad_m16(const float* dy, const void* dy16, float* db, void* workspace, size_t ws_bytes, long long M,
+                                int C, int accumulate, void* stream) {
+  LG_CHECK_ARG((dy || dy16) && db && workspace, "lg_bias_grad: null pointer");
   LG_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0 && C <= 4096, "lg_bias_grad: bad shape M=%lld C=%d", M, C);
   LG_CHECK_ARG(ws_bytes >= lg_bias_grad_workspace_bytes(M, C), "lg_bias_grad: workspace too small");
   long long nb = (M + 255) / 256;
@@ -444,7 +459,7 @@ extern "C" int lg_bias_grad(const float* dy, float* db, void* workspace, size_t 
   const long long rpb = (M + nb - 1) / nb;
   nb = (M + rpb - 1) / rpb;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_kernel, dim3((int)nb), dim3(256), 0, st, dy, (float*)workspace, M, C, rpb);
+  hipLaunchKernelGGL(colsum_kernel, dim3((int)nb), dim3(256), 0, st, dy, (const __bf16*)dy16, (float*)workspace, M, C, rpb);
   LG_CHECK_LAUNCH("lg_bias_grad");
   const int rblocks = (C + 255) / 256;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(rblocks), dim3(256), 0, st, (const float*)workspace, db, (int)nb, 1, 1, 1,

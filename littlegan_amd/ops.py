@@ -111,11 +111,13 @@ def conv2d_s2_fwd(x, pack, bias, cs, dtype, out=None):
 
 
 def conv2d_s2_dgrad(dy, pack, cb, dtype, out=None, dy16=None, out_bf16=False):
-    """dx [B,2Hs,2Ws,cb]; out_bf16: return the gradient as a bf16 tensor (no fp32 copy is written)"""
-    B, Hs, Ws, cs = dy.shape
-    _chk(dy, name="dy")
+    """dx [B,2Hs,2Ws,cb]; out_bf16: return the gradient as a bf16 tensor (no fp32 copy is written).
+    dy may be None when its bf16 mirror dy16 is given and the halo kernel covers the shape (conv_halo_supported)."""
+    B, Hs, Ws, cs = (dy if dy is not None else dy16).shape
+    if dy is not None:
+        _chk(dy, name="dy")
     if dy16 is not None:
-        _chk16(dy16, dy, "dy16")
+        _chk16(dy16, dy if dy is not None else dy16, "dy16")
     if out_bf16:
         out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.bfloat16, device=dy.device)
         o32, o16 = None, out
@@ -133,18 +135,22 @@ def conv2d_s2_dgrad(dy, pack, cb, dtype, out=None, dy16=None, out_bf16=False):
 
 def _wgrad(fn_name, big, small, dw, accumulate, dtype, swap, big16=None, small16=None):
     lib = _lib.load()
-    B, Hs, Ws, cs = small.shape
-    cb = big.shape[3]
-    _chk(big, (B, 2 * Hs, 2 * Ws, cb), "big")
-    _chk(small, name="small")
+    B, Hs, Ws, cs = (small if small is not None else small16).shape
+    cb = (big if big is not None else big16).shape[3]
+    if big is not None:
+        _chk(big, (B, 2 * Hs, 2 * Ws, cb), "big")
+    if small is not None:
+        _chk(small, name="small")
+    if (big is None or small is None) and (big16 is None or small16 is None):
+        raise ValueError("wgrad: an fp32 operand may be omitted only when BOTH bf16 mirrors are given")
     _chk(dw, (5, 5, cb, cs), "dw")
     nbytes = int(lib.lg_wgrad_workspace_bytes(B, Hs, Ws, cb, cs, dtype))
-    ws = workspace(nbytes, big.device, "wgrad")
+    ws = workspace(nbytes, dw.device, "wgrad")
     if big16 is None or small16 is None:
         big16 = small16 = None  # the bf16-source kernel needs both mirrors
     else:
-        _chk16(big16, big, "big16")
-        _chk16(small16, small, "small16")
+        _chk16(big16, big if big is not None else big16, "big16")
+        _chk16(small16, small if small is not None else small16, "small16")
     (a, a16), (b, b16) = ((small, small16), (big, big16)) if swap else ((big, big16), (small, small16))
     e0 = _pb()
     check(getattr(lib, fn_name)(_p(a), _p(a16), _p(b), _p(b16), _p(dw), _p(ws), ws.numel(), B, Hs, Ws, cb, cs,
@@ -174,10 +180,11 @@ def convT_s2_fwd(x, pack, bias, cb, dtype, out=None):
 
 
 def convT_s2_dgrad(dy, pack, cs, dtype, out=None, dy16=None, out_bf16=False):
-    B, H, W, cb = dy.shape
-    _chk(dy, name="dy")
+    B, H, W, cb = (dy if dy is not None else dy16).shape
+    if dy is not None:
+        _chk(dy, name="dy")
     if dy16 is not None:
-        _chk16(dy16, dy, "dy16")
+        _chk16(dy16, dy if dy is not None else dy16, "dy16")
     if out_bf16:
         out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.bfloat16, device=dy.device)
         o32, o16 = None, out
@@ -231,15 +238,32 @@ def convT_s1_tanh_bwd(x, dpre, pack, cs, dtype, dx=None, dw=None, db=None, accum
     return dx
 
 
-def bias_grad(dy, db, accumulate=False):
-    C = dy.shape[-1]
-    M = dy.numel() // C
-    _chk(dy, name="dy")
+def bias_grad(dy, db, accumulate=False, dy16=None):
+    """db (+)= column sums of dy [.., C]; dy16: bf16 copy read instead of dy (dy may then be None)"""
+    t = dy if dy is not None else dy16
+    C = t.shape[-1]
+    M = t.numel() // C
+    if dy is not None:
+        _chk(dy, name="dy")
+    if dy16 is not None:
+        _chk16(dy16, t, "dy16")
     _chk(db, (C,), "db")
     lib = _lib.load()
-    ws = workspace(int(lib.lg_bias_grad_workspace_bytes(M, C)), dy.device, "small")
-    check(lib.lg_bias_grad(_p(dy), _p(db), _p(ws), ws.numel(), M, C, int(accumulate), _stream()), "lg_bias_grad")
+    ws = workspace(int(lib.lg_bias_grad_workspace_bytes(M, C)), t.device, "small")
+    check(lib.lg_bias_grad_m16(_p(dy), _p(dy16), _p(db), _p(ws), ws.numel(), M, C, int(accumulate), _stream()),
+          "lg_bias_grad_m16")
     return db
+
+
+_HALO_OK = {}
+
+
+def conv_halo_supported(mode, dtype, B, Hm, Wm, Cs, N):
+    """mode 0 = conv form ("down": M grid Hm x Wm is the SMALL map), 1 = convT form ("up").  Host-side query."""
+    key = (mode, dtype, B, Hm, Wm, Cs, N)
+    if key not in _HALO_OK:
+        _HALO_OK[key] = bool(_lib.load().lg_conv_halo_supported(mode, dtype, B, Hm, Wm, Cs, N))
+    return _HALO_OK[key]
 
 
 # ------------------------------------------------------------------ instance norm
