@@ -118,12 +118,13 @@ def conv2d_s2_dgrad(dy, pack, cb, dtype, out=None, dy16=None, out_bf16=False):
         _chk(dy, name="dy")
     if dy16 is not None:
         _chk16(dy16, dy if dy is not None else dy16, "dy16")
+    dev = (dy if dy is not None else dy16).device
     if out_bf16:
-        out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.bfloat16, device=dy.device)
+        out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.bfloat16, device=dev)
         o32, o16 = None, out
     else:
         if out is None:
-            out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.float32, device=dy.device)
+            out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.float32, device=dev)
         _chk(out, (B, 2 * Hs, 2 * Ws, cb), "out")
         o32, o16 = out, None
     e0 = _pb()
@@ -185,12 +186,13 @@ def convT_s2_dgrad(dy, pack, cs, dtype, out=None, dy16=None, out_bf16=False):
         _chk(dy, name="dy")
     if dy16 is not None:
         _chk16(dy16, dy if dy is not None else dy16, "dy16")
+    dev = (dy if dy is not None else dy16).device
     if out_bf16:
-        out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.bfloat16, device=dy.device)
+        out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.bfloat16, device=dev)
         o32, o16 = None, out
     else:
         if out is None:
-            out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.float32, device=dy.device)
+            out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.float32, device=dev)
         _chk(out, (B, H // 2, W // 2, cs), "out")
         o32, o16 = out, None
     e0 = _pb()
