@@ -124,8 +124,9 @@ int lg_dense_fwd(const float* x, const float* w, const float* bias, float* y, in
 int lg_dense_wgrad(const float* x, const float* dy, float* dw, float* db, int B, int K, int N, int accumulate,
                    void* stream);
 /* p[B][1+c] = sigmoid(x[B][K] @ [wpr | wc] + [bpr | bc]) : column 0 = output_pr, 1.. = output_cond */
-int lg_heads_fwd(const float* x, const float* wpr, const float* bpr, const float* wc, const float* bc, float* p, int B,
-                 int K, int c, void* stream);
+size_t lg_heads_fwd_workspace_bytes(int B, int K, int c);
+int lg_heads_fwd(const float* x, const float* wpr, const float* bpr, const float* wc, const float* bc, float* p,
+                 void* workspace, size_t ws_bytes, int B, int K, int c, void* stream);
 int lg_heads_dgrad(const float* dz, const float* wpr, const float* wc, float* dx, int B, int K, int c, void* stream);
 int lg_heads_wgrad(const float* x, const float* dz, float* dwpr, float* dbpr, float* dwc, float* dbc, int B, int K,
                    int c, int accumulate, void* stream);

@@ -49,7 +49,8 @@ SIGNATURES = {
     "lg_instnorm_leaky_bwd": (I, [P, P, P, I, P, P, P, P, P, Z, I, L, I, I, F, I, P]),
     "lg_dense_fwd": (I, [P, P, P, P, I, I, I, P]),
     "lg_dense_wgrad": (I, [P, P, P, P, I, I, I, I, P]),
-    "lg_heads_fwd": (I, [P, P, P, P, P, P, I, I, I, P]),
+    "lg_heads_fwd_workspace_bytes": (Z, [I, I, I]),
+    "lg_heads_fwd": (I, [P, P, P, P, P, P, P, Z, I, I, I, P]),
     "lg_heads_dgrad": (I, [P, P, P, P, I, I, I, P]),
     "lg_heads_wgrad": (I, [P, P, P, P, P, P, I, I, I, I, P]),
     "lg_bce_heads_loss_fwd_bwd": (I, [P, P, F, F, F, P, P, I, I, I, P]),

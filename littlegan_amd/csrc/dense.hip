@@ -59,7 +59,19 @@ __global__ __launch_bounds__(256) void dense_wgrad_kernel(const float* __restric
     __syncthreads();
     if (n < N) {
       const int be = min(BT, B - bb);
-      for (int b = 0; b < be; ++b) {
+      int b = 0;
+      for (; b + 8 <= be; b += 8) {  // 8 independent 16-B loads in flight per thread
+        f32x4 dv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dv[u] = *reinterpret_cast<const f32x4*>(dy + (long long)(bb + b + u) * N + n);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          accb += dv[u];
+#pragma unroll
+          for (int k = 0; k < KT; ++k) acc[k] += xs[(b + u) * KT + k] * dv[u];
+        }
+      }
+      for (; b < be; ++b) {
         const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + (long long)(bb + b) * N + n);
         accb += dv;
 #pragma unroll

@@ -373,7 +373,10 @@ def heads_fwd(x, wpr, bpr, wc, bc, out=None):
     if out is None:
         out = torch.empty(B, 1 + c, dtype=torch.float32, device=x.device)
     _chk(out, (B, 1 + c), "out")
-    check(_lib.load().lg_heads_fwd(_p(x), _p(wpr), _p(bpr), _p(wc), _p(bc), _p(out), B, K, c, _stream()), "lg_heads_fwd")
+    lib = _lib.load()
+    ws = workspace(int(lib.lg_heads_fwd_workspace_bytes(B, K, c)), x.device, "small")
+    check(lib.lg_heads_fwd(_p(x), _p(wpr), _p(bpr), _p(wc), _p(bc), _p(out), _p(ws), ws.numel(), B, K, c, _stream()),
+          "lg_heads_fwd")
     return out
 
 
