@@ -110,7 +110,8 @@ int lg_instnorm_leaky_stats(const float* x, float* stats, const float* gamma, co
 int lg_instnorm_stats_finalize(const void* partials, int nparts, float* stats, const float* gamma, const float* beta,
                                int B, void* stream);
 /* y = [post_leaky](a*([pre_leaky](x) - mu) + beta) [+ skip] ; y16 (may be null): bf16 mirror of y, the MFMA operand
- * image the bf16 conv / wgrad kernels consume instead of re-reading and re-rounding the fp32 tensor */
+ * image the bf16 conv / wgrad kernels consume instead of re-reading and re-rounding the fp32 tensor; y may be
+ * null when only the mirror is wanted (at least one of y, y16) */
 int lg_instnorm_leaky_apply(const float* x, const float* stats, const float* skip, float* y, void* y16, int B,
                             long long L, int pre_leaky, int post_leaky, float alpha, void* stream);
 /* g = dL/dy (before skip), fp32 or (g_is_bf16) bf16 -> dx fp32 and/or its bf16 mirror dx16 (at least one non-null);

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ x,
       v[k] = t;
     }
     if (skip) v += *reinterpret_cast<const f32x4*>(skip + i * 4);
-    *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    if (y) *reinterpret_cast<f32x4*>(y + i * 4) = v;
     if (y16) {  // bf16 mirror = exactly the MFMA operand the consumers would round to themselves
       bf16x4 w;
       w[0] = (__bf16)v[0]; w[1] = (__bf16)v[1]; w[2] = (__bf16)v[2]; w[3] = (__bf16)v[3];
@@ -285,7 +285,7 @@ extern "C" int lg_instnorm_stats_finalize(const void* partials, int nparts, floa
 // y = [post_leaky] (a_n * ([pre_leaky](x) - mu_n) + beta) [+ skip]
 extern "C" int lg_instnorm_leaky_apply(const float* x, const float* stats, const float* skip, float* y, void* y16, int B,
                                        long long L, int pre_leaky, int post_leaky, float alpha, void* stream) {
-  LG_CHECK_ARG(x && stats && y, "lg_instnorm_leaky_apply: null pointer");
+  LG_CHECK_ARG(x && stats && (y || y16), "lg_instnorm_leaky_apply: null pointer");
   LG_CHECK_ARG(B > 0 && L > 0 && L % 4 == 0, "lg_instnorm_leaky_apply: bad shape B=%d L=%lld", B, L);
   const long long total4 = (long long)B * L / 4;
   hipLaunchKernelGGL(apply_kernel, dim3(ew_blocks(total4)), dim3(256), 0, (hipStream_t)stream, x, stats, skip, y,

@@ -74,7 +74,9 @@ class EagerTrainer:
         d_in[:B].copy_(new_image)
         fake = G([noise, c2], ctx_g, out=d_in[B:])
         ctx_d: dict = {}
-        p = D.forward_packed(d_in, ctx_d)  # [2B, 1+c]: rows [0,B) real, [B,2B) fake
+        run_adj = bool(a.train_adj and batch_no > 10)
+        # the Adjuster reuses D's encoder maps of `fake` as its skip inputs: keep the fp32 maps only then
+        p = D.forward_packed(d_in, ctx_d, keep_maps=run_adj)  # [2B, 1+c]: rows [0,B) real, [B,2B) fake
 
         # ---- disc tape (eager_trainer.py:139,145): 2*BCE(c1,real_c) + BCE(.98,real_pr) + BCE(.02,fake_pr)
         dz = torch.empty(2 * B, 1 + c, dtype=torch.float32, device=self.device)
@@ -94,7 +96,6 @@ class EagerTrainer:
 
         # ---- adjuster branch (eager_trainer.py:152-164)
         adj_image = None
-        run_adj = bool(a.train_adj and batch_no > 10)
         if run_adj:
             adj_in_cond = (torch.cat([c2, c1], 0) + 1.0) * 0.5
             adj_t_cond = torch.cat([c2, c1], 0)
@@ -106,7 +107,7 @@ class EagerTrainer:
             tails = [ctx_d["enc"][k][0][B:] for k in (1, 2, 3)] + [ctx_d["heads_x"][B:].view(B, i_d, i_d, f0)]
             adj_image = A([adj_in_img, adj_in_cond], ctx_a, enc_tails=tails)
             ctx_d2: dict = {}
-            p_a = D.forward_packed(adj_image, ctx_d2)
+            p_a = D.forward_packed(adj_image, ctx_d2, keep_maps=False)
             dz_a = torch.empty(2 * B, 1 + c, dtype=torch.float32, device=self.device)
             ops.bce_heads_loss(p_a, adj_t_cond, soft(1.0), 1.0, 1.0, self.losses["adj"], dz_a, False)
             g_adj = D.backward(ctx_d2, dz_a, need_wgrad=False, need_input_grad=True)

@@ -117,8 +117,10 @@ class Encoder(_ConvStack):
     def _bias_dim(cb, cs):
         return cs
 
-    def __call__(self, inputs, ctx: Optional[dict] = None, tails=None):
-        """tails (optional): the 4 maps this encoder already produced for MORE samples that follow `inputs` in the
+    def __call__(self, inputs, ctx: Optional[dict] = None, tails=None, keep_maps: bool = True):
+        """keep_maps=False: the caller only uses the LAST map; in the bf16 path the fp32 copies of maps 1-3 are then
+        not written where the next conv reads the bf16 mirror (their list entries are None).
+        tails (optional): the 4 maps this encoder already produced for MORE samples that follow `inputs` in the
         batch (same weights); they are appended to the outputs instead of being recomputed (the Adjuster's input is
         [img1 ; fake] and D has just encoded `fake`).  Every op is per-sample, so the result is identical."""
         x = inputs
@@ -136,7 +138,9 @@ class Encoder(_ConvStack):
                 st = ops.instnorm_stats(z, gm, bt, 0, a)
             h16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if m16 else None
             if tails is None:
-                h = ops.instnorm_apply(z, st, None, 0, 1, a, out16=h16)
+                drop32 = (m16 and not keep_maps and i < 4 and ops.conv_halo_supported(
+                    0, self.dtype, z.shape[0], z.shape[1] // 2, z.shape[2] // 2, cs, self.chans[i][1]))
+                h = ops.instnorm_apply(z, st, None, 0, 1, a, out16=h16, want_f32=not drop32)
                 outs.append(h)
             else:
                 full = torch.empty((B1 + tails[i - 1].shape[0],) + tuple(z.shape[1:]), dtype=torch.float32, device=z.device)
@@ -159,7 +163,8 @@ class Encoder(_ConvStack):
             cb, cs = self.chans[i - 1]
             x, z, st, x16 = ctx["enc"][i - 1]
             if rows is not None:
-                x, z, st = x[rows], z[rows], st[rows]
+                z, st = z[rows], st[rows]
+                x = x[rows] if x is not None else None
                 x16 = x16[rows] if x16 is not None else None
             dgm = self._g[f"norm{i}.gamma"] if need_wgrad else None
             dbt = self._g[f"norm{i}.beta"] if need_wgrad else None
@@ -208,7 +213,10 @@ class Decoder(_ConvStack):
                 st = ops.instnorm_stats(z, gm, bt, 0, a)
             skip = add[i] if i < 4 else None
             h16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if (m16 and i < 4) else None
-            h = ops.instnorm_apply(z, st, skip, 0, 1, a, out16=h16)
+            # levels 1-3 feed only the next transposed conv and its weight gradient: both read the bf16 mirror
+            drop32 = (h16 is not None and ops.conv_halo_supported(1, self.dtype, z.shape[0], z.shape[1], z.shape[2], cb,
+                                                                  self.chans[i][0]))
+            h = ops.instnorm_apply(z, st, skip, 0, 1, a, out16=h16, want_f32=not drop32)
             saved.append((x, z, st, x16))
             x, x16 = h, h16
         if ctx is not None:
@@ -356,8 +364,8 @@ class Discriminator(_Module):
     def weights(self):
         return self.encoder.weights + [self._w[n] for n in self._names]
 
-    def forward_packed(self, image, ctx: Optional[dict] = None):
-        outs = self.encoder(image, ctx)
+    def forward_packed(self, image, ctx: Optional[dict] = None, keep_maps: bool = True):
+        outs = self.encoder(image, ctx, keep_maps=keep_maps)
         x = outs[3].view(image.shape[0], -1)
         p = ops.heads_fwd(x, self._w["dense_pr.kernel"], self._w["dense_pr.bias"], self._w["dense_cond.kernel"],
                           self._w["dense_cond.bias"])

@@ -289,7 +289,8 @@ def _chk16(t, like, name):
     return t
 
 
-def instnorm_apply(x, stats, skip, pre_leaky, post_leaky, alpha, out=None, out16=None):
+def instnorm_apply(x, stats, skip, pre_leaky, post_leaky, alpha, out=None, out16=None, want_f32=True):
+    """want_f32=False: only the bf16 mirror out16 is written (returns None)."""
     B = x.shape[0]
     Ln = x.numel() // B
     _chk(x, name="x")
@@ -298,11 +299,16 @@ def instnorm_apply(x, stats, skip, pre_leaky, post_leaky, alpha, out=None, out16
         _chk(skip, name="skip")
         if skip.numel() != x.numel():
             raise ValueError("instnorm_apply: skip has a different size")
-    if out is None:
-        out = torch.empty_like(x)
-    _chk(out, x.shape, "out")
+    if not want_f32:
+        if out16 is None:
+            raise ValueError("instnorm_apply: want_f32=False needs out16")
+        out = None
+    else:
+        if out is None:
+            out = torch.empty_like(x)
+        _chk(out, x.shape, "out")
     if out16 is not None:
-        _chk16(out16, out, "out16")
+        _chk16(out16, x, "out16")
     check(_lib.load().lg_instnorm_leaky_apply(_p(x), _p(stats), _p(skip), _p(out), _p(out16), B, Ln, int(pre_leaky),
                                               int(post_leaky), float(alpha), _stream()), "lg_instnorm_leaky_apply")
     return out
@@ -446,17 +452,17 @@ def _fwd_stats(fn_name, x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma
     Returns stats [B, NSTAT] or None (caller then runs instnorm_stats on the output)."""
     import ctypes
     lib = _lib.load()
-    ws = workspace(B * 1024 * 24, x.device, "statpart")  # >= B * nparts * 3 doubles for every layer shape (nparts <= 1024)
+    ws = workspace(B * 1024 * 24, out.device, "statpart")  # >= B * nparts * 3 doubles for every layer shape (nparts <= 1024)
     nparts = ctypes.c_int(0)
     e0 = _pb()
     if x16 is not None:
-        _chk16(x16, x, "x16")
+        _chk16(x16, x if x is not None else x16, "x16")
     check(getattr(lib, fn_name)(_p(x), _p(x16), _p(pack), _p(bias), _p(out), B, Hs, Ws, cb, cs, dtype, _p(ws), ws.numel(),
                                 ctypes.addressof(nparts), _stream()), fn_name)
     _pe(e0, tag, flops)
     if nparts.value <= 0:
         return None
-    stats = torch.empty(B, NSTAT, dtype=torch.float32, device=x.device)
+    stats = torch.empty(B, NSTAT, dtype=torch.float32, device=out.device)
     check(lib.lg_instnorm_stats_finalize(_p(ws), nparts.value, _p(stats), _p(gamma), _p(beta), B, _stream()),
           "lg_instnorm_stats_finalize")
     return stats
@@ -464,22 +470,24 @@ def _fwd_stats(fn_name, x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma
 
 def conv2d_s2_fwd_stats(x, pack, bias, cs, dtype, gamma, beta, x16=None):
     """conv2d_s2_fwd + the InstanceNormalization statistics of its output -> (y, stats or None)."""
-    B, H, W, cb = x.shape
-    _chk(x, name="x")
+    B, H, W, cb = (x if x is not None else x16).shape  # x may be None when the bf16 mirror feeds the halo kernel
+    if x is not None:
+        _chk(x, name="x")
     _chk(bias, (cs,), "bias")
     if H % 2 or W % 2:
         raise ValueError("conv2d_s2_fwd_stats: H and W must be even")
-    out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.float32, device=x.device)
+    out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.float32, device=bias.device)
     st = _fwd_stats("lg_conv2d_s2_fwd_stats", x, x16, pack, bias, out, B, H // 2, W // 2, cb, cs, dtype, gamma, beta,
                     "conv_igemm_patch" if cb == 3 else "conv_igemm_down", 50.0 * B * (H // 2) * (W // 2) * cb * cs)
     return out, st
 
 
 def convT_s2_fwd_stats(x, pack, bias, cb, dtype, gamma, beta, x16=None):
-    B, Hs, Ws, cs = x.shape
-    _chk(x, name="x")
+    B, Hs, Ws, cs = (x if x is not None else x16).shape
+    if x is not None:
+        _chk(x, name="x")
     _chk(bias, (cb,), "bias")
-    out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.float32, device=x.device)
+    out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.float32, device=bias.device)
     st = _fwd_stats("lg_convT_s2_fwd_stats", x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, "conv_igemm_up",
                     50.0 * B * Hs * Ws * cb * cs)
     return out, st
