@@ -88,6 +88,16 @@ int lg_convT_s1_tanh_bwd(const float* x, const float* dpre, const void* pack, fl
                          void* workspace, size_t ws_bytes, int B, int H, int W, int cb, int cs, int accumulate,
                          int dtype, void* stream);
 size_t lg_convT_s1_bwd_workspace_bytes(int B, int H, int W, int cb, int cs, int dtype);
+/* bf16 path of the 3-channel layers (this one and the data gradient of Encoder.conv1): 1 if the kernels of this shape
+ * read the bf16 mirror of the wide operand alone, so that its fp32 copy need not exist (H, W: the wide operand's map) */
+int lg_n3_m16_supported(int H, int W, int cb, int cs, int dtype);
+/* as above with x16 = bf16 mirror of x (x may be null where lg_n3_m16_supported); dx16 (may be null): the data
+ * gradient is written as bf16 there instead of fp32 to dx (give at most one of dx, dx16) */
+int lg_convT_s1_tanh_fwd_m16(const float* x, const void* x16, const void* pack, const float* bias, float* y, int B, int H,
+                             int W, int cb, int cs, int dtype, void* stream);
+int lg_convT_s1_tanh_bwd_m16(const float* x, const void* x16, const float* dpre, const void* pack, float* dx, void* dx16,
+                             float* dw, float* db, void* workspace, size_t ws_bytes, int B, int H, int W, int cb, int cs,
+                             int accumulate, int dtype, void* stream);
 
 /* bias gradient of any conv layer: db[C] (+)= column sums of dy[M][C]  (C % 4 == 0) */
 size_t lg_bias_grad_workspace_bytes(long long M, int C);

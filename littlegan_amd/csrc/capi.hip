@@ -29,6 +29,10 @@ extern "C" size_t lg_conv_pack_raw_offset(int cb, int cs, int dtype);
 extern "C" int lg_n3_s1t_fwd_try(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C,
                                  void* stream);
 extern "C" int lg_n3_up_try(const float* src, const float* w, float* out, int B, int H, int W, int C, void* stream);
+extern "C" int lg_n3_p16_supported(int H, int W, int C);
+extern "C" int lg_n3_s1t_fwd_p16_try(const void* x16, const float* w, const float* bias, float* y, int B, int H, int W,
+                                     int C, void* stream);
+extern "C" int lg_n3_up_p16_try(const void* src16, const float* w, float* out, int B, int H, int W, int C, void* stream);
 static bool n3_enabled() {
   static int v = -1;
   if (v < 0) v = getenv("LG_NO_N3") ? 0 : 1;  // A/B switch
@@ -91,6 +95,11 @@ extern "C" int lg_conv2d_s2_dgrad_m16(const float* dy, const void* dy16, const v
                                       int Hs, int Ws, int cb, int cs, int dtype, void* stream) {
   if (cb == 3) {
     LG_CHECK_ARG(dx && !dx16, "lg_conv2d_s2_dgrad_m16: the 3-channel image gradient is fp32 only");
+    if (dtype == LG_DT_BF16 && dy16 && n3_enabled()) {  // bf16 path: tap-product GEMM straight from the bf16 mirror
+      const int rc = lg_n3_up_p16_try(dy16, raw_pack(pack, cb, cs, dtype), dx, B, Hs, Ws, cs, stream);
+      if (rc != LG_ERR_UNSUPPORTED) return rc;
+    }
+    LG_CHECK_ARG(dy, "lg_conv2d_s2_dgrad_m16: this shape needs the fp32 gradient (see lg_n3_m16_supported)");
     return run_up(dy, pack, nullptr, dx, B, Hs, Ws, cb, cs, dtype, stream);
   }
   return lg_conv_igemm_ex(MODE_UP, dtype, dy, dy16, up_pack(pack, cb, cs, dtype), nullptr, dx, dx16, B, Hs, Ws, cs, cb, 0, 0,
@@ -134,6 +143,21 @@ extern "C" int lg_convT_s2_dgrad(const float* dy, const void* pack, float* dx, i
 extern "C" int lg_convT_s2_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t ws_bytes, int B,
                                  int Hs, int Ws, int cb, int cs, int accumulate, int dtype, void* stream) {
   return lg_conv_wgrad(dy, x, dw, workspace, ws_bytes, B, Hs, Ws, cb, cs, 2, 1, accumulate, dtype, stream);
+}
+
+// 1 if the 3-channel layers of this shape run from the bf16 mirror alone in the bf16 path (no fp32 operand needed)
+extern "C" int lg_n3_m16_supported(int H, int W, int cb, int cs, int dtype) {
+  return (dtype == LG_DT_BF16 && cb == 3 && n3_enabled() && lg_n3_p16_supported(H, W, cs)) ? 1 : 0;
+}
+
+extern "C" int lg_convT_s1_tanh_fwd_m16(const float* x, const void* x16, const void* pack, const float* bias, float* y,
+                                        int B, int H, int W, int cb, int cs, int dtype, void* stream) {
+  if (x16 && lg_n3_m16_supported(H, W, cb, cs, dtype)) {
+    const int rc = lg_n3_s1t_fwd_p16_try(x16, raw_pack(pack, cb, cs, dtype), bias, y, B, H, W, cs, stream);
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+  }
+  LG_CHECK_ARG(x, "lg_convT_s1_tanh_fwd_m16: this shape needs the fp32 input (see lg_n3_m16_supported)");
+  return lg_convT_s1_tanh_fwd(x, pack, bias, y, B, H, W, cb, cs, dtype, stream);
 }
 
 extern "C" int lg_convT_s1_tanh_fwd(const float* x, const void* pack, const float* bias, float* y, int B, int H, int W,
@@ -183,21 +207,37 @@ extern "C" size_t lg_convT_s1_bwd_workspace_bytes(int B, int H, int W, int cb, i
   return a > b ? a : b;
 }
 
+extern "C" int lg_convT_s1_tanh_bwd_m16(const float* x, const void* x16, const float* dpre, const void* pack, float* dx,
+                                        void* dx16, float* dw, float* db, void* workspace, size_t ws_bytes, int B, int H,
+                                        int W, int cb, int cs, int accumulate, int dtype, void* stream);
+
 extern "C" int lg_convT_s1_tanh_bwd(const float* x, const float* dpre, const void* pack, float* dx, float* dw, float* db,
                                     void* workspace, size_t ws_bytes, int B, int H, int W, int cb, int cs,
                                     int accumulate, int dtype, void* stream) {
+  return lg_convT_s1_tanh_bwd_m16(x, nullptr, dpre, pack, dx, nullptr, dw, db, workspace, ws_bytes, B, H, W, cb, cs,
+                                  accumulate, dtype, stream);
+}
+
+// x16 (optional, bf16 path): bf16 mirror of x read by the weight-gradient kernel (x may then be null where
+// lg_n3_m16_supported); dx16 (optional): the data gradient is written as bf16 there instead of fp32 to dx
+extern "C" int lg_convT_s1_tanh_bwd_m16(const float* x, const void* x16, const float* dpre, const void* pack, float* dx,
+                                        void* dx16, float* dw, float* db, void* workspace, size_t ws_bytes, int B, int H,
+                                        int W, int cb, int cs, int accumulate, int dtype, void* stream) {
   LG_CHECK_ARG(cb == 3, "lg_convT_s1_tanh_bwd: only image_channel == 3 is supported (got %d)", cb);
   LG_CHECK_ARG(dpre && pack && workspace, "lg_convT_s1_tanh_bwd: null pointer");
   LG_CHECK_ARG(ws_bytes >= lg_convT_s1_bwd_workspace_bytes(B, H, W, cb, cs, dtype),
                "lg_convT_s1_tanh_bwd: workspace too small");
+  LG_CHECK_ARG(!(dx && dx16), "lg_convT_s1_tanh_bwd: give dx or dx16, not both");
   int rc;
-  if (dx) {  // dx[i,ci] = sum_k,co dpre[i+k-2,co] W[k,co,ci]  -> patch conv, stride 1, pad 2
-    rc = lg_conv_igemm(MODE_PATCH, dtype, dpre, pack, nullptr, dx, B, H, W, 3, cs, 0, 1, 2, stream);
+  if (dx || dx16) {  // dx[i,ci] = sum_k,co dpre[i+k-2,co] W[k,co,ci]  -> patch conv, stride 1, pad 2
+    rc = lg_conv_igemm_ex(MODE_PATCH, dtype, dpre, nullptr, pack, nullptr, dx, dx16, B, H, W, 3, cs, 0, 1, 2, nullptr, 0,
+                          nullptr, stream);
     if (rc) return rc;
   }
   if (dw) {
-    LG_CHECK_ARG(x, "lg_convT_s1_tanh_bwd: x is null but dw requested");
-    rc = lg_conv_wgrad(dpre, x, dw, workspace, ws_bytes, B, H, W, 3, cs, 1, 2, accumulate, dtype, stream);
+    LG_CHECK_ARG(x || x16, "lg_convT_s1_tanh_bwd: x is null but dw requested");
+    rc = lg_conv_wgrad_m16(dpre, nullptr, x, dtype == LG_DT_BF16 ? x16 : nullptr, dw, workspace, ws_bytes, B, H, W, 3, cs, 1,
+                           2, accumulate, dtype, stream);
     if (rc) return rc;
   }
   if (db) {

@@ -122,9 +122,11 @@ __global__ __launch_bounds__(256) void n3_up_kernel(const float* __restrict__ sr
 // 3-channel tensor (per-lane row offset + per-k pixel base), B[k][j] is the small tensor's pixel row.
 // Block = 4 waves, pixel tile 8x16: wave w reduces pixels [32w, 32w+32) and writes its own fp32 slab.
 // --------------------------------------------------------------------------------------------------------------
-template <int NT>
+// S16: `small` is read from its bf16 mirror (bf16 path; the values are widened exactly, the MFMA stays f32).
+template <int NT, bool S16>
 __global__ __launch_bounds__(256) void n3_wgrad_kernel(const float* __restrict__ big3, const float* __restrict__ small,
-                                                       float* __restrict__ slab, int B, int H, int W, int s, int pad) {
+                                                       const __bf16* __restrict__ small16, float* __restrict__ slab,
+                                                       int B, int H, int W, int s, int pad) {
   constexpr int Cs = NT * 32, TH = 8, TW = 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int HH = s * TH + 4, HW = s * TW + 4;  // halo of the 3-channel tensor (taps span 5 pixels)
@@ -157,8 +159,15 @@ __global__ __launch_bounds__(256) void n3_wgrad_kernel(const float* __restrict__
     for (int i = threadIdx.x; i < TH * TW * (Cs / 4); i += 256) {
       const int pix = i / (Cs / 4), c4 = i % (Cs / 4);
       const int yy = y0 + pix / TW, xx = x0 + pix % TW;
-      *reinterpret_cast<f32x4*>(sB + pix * Cs + c4 * 4) =
-          *reinterpret_cast<const f32x4*>(small + ((long long)(n * H + yy) * W + xx) * Cs + c4 * 4);
+      const long long go = ((long long)(n * H + yy) * W + xx) * Cs + c4 * 4;
+      f32x4 v;
+      if constexpr (S16) {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(small16 + go);
+        v = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+      } else {
+        v = *reinterpret_cast<const f32x4*>(small + go);
+      }
+      *reinterpret_cast<f32x4*>(sB + pix * Cs + c4 * 4) = v;
     }
     for (int i = threadIdx.x; i < HH * HW * 3; i += 256) {
       const int hp = i / 3, c3 = i - hp * 3;
@@ -253,19 +262,28 @@ extern "C" size_t lg_n3_wgrad_workspace_bytes(int B, int H, int W, int Cs) {
   return (size_t)wgrad_blocks(ntiles > 0 ? ntiles : 1) * 4 * 75 * Cs * sizeof(float);
 }
 
-extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, float* dw, void* workspace, size_t ws_bytes, int B,
-                               int H, int W, int Cs, int s, int pad, int accumulate, void* stream) {
+extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void* small16, float* dw, void* workspace,
+                               size_t ws_bytes, int B, int H, int W, int Cs, int s, int pad, int accumulate, void* stream) {
   if (H % 8 || W % 16 || (Cs != 32 && Cs != 64) || (s != 1 && s != 2)) return LG_ERR_UNSUPPORTED;
   if (ws_bytes < lg_n3_wgrad_workspace_bytes(B, H, W, Cs)) return LG_ERR_UNSUPPORTED;
+  if (!big3 || (!small && !small16)) return LG_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int ntiles = B * (H / 8) * (W / 16), nblk = wgrad_blocks(ntiles);
   const size_t lds = (size_t)(128 * Cs + (s * 8 + 4) * (s * 16 + 4) * 3 + 4) * 4;
+  const __bf16* s16 = (const __bf16*)small16;
+  static bool a = false;
+  if (!a) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(n3_wgrad_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(n3_wgrad_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    a = true;
+  }
+  float* slab = (float*)workspace;
   if (Cs == 32) {
-    hipLaunchKernelGGL(n3_wgrad_kernel<1>, dim3(nblk), dim3(256), lds, st, big3, small, (float*)workspace, B, H, W, s, pad);
+    if (s16) hipLaunchKernelGGL((n3_wgrad_kernel<1, true>), dim3(nblk), dim3(256), lds, st, big3, small, s16, slab, B, H, W, s, pad);
+    else hipLaunchKernelGGL((n3_wgrad_kernel<1, false>), dim3(nblk), dim3(256), lds, st, big3, small, s16, slab, B, H, W, s, pad);
   } else {
-    static bool a = false;
-    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(n3_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); a = true; }
-    hipLaunchKernelGGL(n3_wgrad_kernel<2>, dim3(nblk), dim3(256), lds, st, big3, small, (float*)workspace, B, H, W, s, pad);
+    if (s16) hipLaunchKernelGGL((n3_wgrad_kernel<2, true>), dim3(nblk), dim3(256), lds, st, big3, small, s16, slab, B, H, W, s, pad);
+    else hipLaunchKernelGGL((n3_wgrad_kernel<2, false>), dim3(nblk), dim3(256), lds, st, big3, small, s16, slab, B, H, W, s, pad);
   }
   LG_CHECK_LAUNCH("lg_n3_wgrad");
   const int n = 75 * Cs;

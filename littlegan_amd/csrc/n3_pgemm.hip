@@ -1,0 +1,183 @@
+// bf16-path kernels of the two forward-shaped 3-channel layers, as a "tap-product GEMM + shift-sum":
+//
+//   out[o][c3] = sum_{tap,c} src[o + d(tap)][c] * W[tap][c3][c]
+//              = sum_tap P[o + d(tap)][tap][c3],      P[q][tap][c3] = sum_c src[q][c] * W[tap][c3][c]
+//
+// P is a dense GEMM  [pixels x C] x [C x 75]  — every MFMA column is a real (tap, c3) output instead of 3 useful
+// columns out of 32 — and the sum over taps is 75 LDS reads + adds per pixel.  A block takes one 16x16 tile, keeps
+// the bf16 source halo as MFMA A fragments in registers (loaded straight from the bf16 mirror, 16 B per lane), and
+// runs one pass per filter ROW ky: the 16-column B fragment is (kx, c3) = 15 real columns, the 16x16 fp32 products
+// go to LDS, and every thread adds the 5 x 3 values its pixel receives from that row.
+//   s1t_fwd_p16 : y[B,H,W,3] = tanh(convT_s1(x16[B,H,W,C]) + b)           /root/reference/model.py:86-87,104
+//   up_p16      : dimg[B,2H,2W,3] = conv2d_backprop_input(dz16[B,H,W,C])  (gradient of Encoder.conv1, model.py:15)
+// Weights come from the verbatim fp32 copy in the pack (pack.hip, cb == 3) and are rounded to bf16 (RNE) here, the
+// same rounding the packed MFMA operands get; accumulation is fp32 throughout.
+#include "lg_common.h"
+
+namespace {
+
+constexpr int TS = 16;  // tile side (pixels of the M grid)
+constexpr int PR = 17;  // LDS row pitch of P (floats): 16 columns + 1 -> the shift-sum reads are conflict-free
+
+__device__ __forceinline__ bf16x8 cvt8(const float* p) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  bf16x8 v;
+  v[0] = (__bf16)a[0]; v[1] = (__bf16)a[1]; v[2] = (__bf16)a[2]; v[3] = (__bf16)a[3];
+  v[4] = (__bf16)b[0]; v[5] = (__bf16)b[1]; v[6] = (__bf16)b[2]; v[7] = (__bf16)b[3];
+  return v;
+}
+__device__ __forceinline__ bf16x8 zero8() {
+  return __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+}
+
+// B fragments of filter row ky: column n = kx*3 + c3 (n == 15 is padding), k = channel.  16x16x32 layout: lane l holds
+// B[k = 8(l>>4) + j][col l&15].  w is [5][5][3][C] fp32.
+template <int C>
+__device__ __forceinline__ void load_bfrags(const float* __restrict__ w, int lane, bf16x8 (&bf)[5][C / 32]) {
+  const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+    for (int kh = 0; kh < C / 32; ++kh)
+      bf[ky][kh] = n < 15 ? cvt8(w + ((long long)(ky * 5) * 3 + n) * C + kh * 32 + g * 8) : zero8();
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void s1t_fwd_p16_kernel(const __bf16* __restrict__ x16, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                          int H, int W) {
+  constexpr int HS = TS + 4, NQ = HS * HS, NMT = NQ / 16, MTW = (NMT + 3) / 4, KH = C / 32;
+  static_assert(NQ % 16 == 0, "halo pixels must fill whole MFMA row tiles");
+  __shared__ float sP[NQ * PR];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int tpx = W / TS, tpi = tpx * (H / TS);
+  const int n = blockIdx.x / tpi, tt = blockIdx.x % tpi;
+  const int y0 = (tt / tpx) * TS, x0 = (tt % tpx) * TS;
+
+  bf16x8 bf[5][KH], af[MTW][KH];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) {  // A fragments: lane l holds A[row l&15][k = 8(l>>4) + j]
+    const int mt = wid + 4 * i, q = mt * 16 + r;
+    const int sy = y0 - 2 + q / HS, sx = x0 - 2 + q % HS;
+    const bool ok = mt < NMT && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+      af[i][kh] = ok ? *reinterpret_cast<const bf16x8*>(x16 + ((long long)(n * H + sy) * W + sx) * C + kh * 32 + g * 8) : zero8();
+  }
+  load_bfrags<C>(w, lane, bf);
+
+  const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
+  float acc[3] = {bias[0], bias[1], bias[2]};
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky) {
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      const int mt = wid + 4 * i;
+      if (mt < NMT) {
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kh], bf[ky][kh], c, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sP[(mt * 16 + 4 * g + e) * PR + r] = c[e];  // C: col = lane&15, row = 4(lane>>4)+e
+      }
+    }
+    __syncthreads();
+    // y[o] = sum_k x[o + 2 - k] W[k]: halo pixel (ly + 4 - ky, lx + 4 - kx), halo origin = tile origin - 2
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) {
+      const float* pp = sP + ((ly + 4 - ky) * HS + (lx + 4 - kx)) * PR + kx * 3;
+      acc[0] += pp[0]; acc[1] += pp[1]; acc[2] += pp[2];
+    }
+    __syncthreads();
+  }
+  float* o = y + ((long long)(n * H + y0 + ly) * W + x0 + lx) * 3;
+  o[0] = tanhf(acc[0]); o[1] = tanhf(acc[1]); o[2] = tanhf(acc[2]);
+}
+
+// one thread per SOURCE pixel q of a 16x16 tile; it owns the 2x2 output quad (4 parity classes x 3 channels)
+template <int C>
+__global__ __launch_bounds__(256) void up_p16_kernel(const __bf16* __restrict__ src16, const float* __restrict__ w,
+                                                     float* __restrict__ out, int B, int H, int W) {
+  constexpr int HS = TS + 2, NQ = HS * HS, NMT = (NQ + 15) / 16, MTW = (NMT + 3) / 4, KH = C / 32;
+  __shared__ float sP[NMT * 16 * PR];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int tpx = W / TS, tpi = tpx * (H / TS);
+  const int n = blockIdx.x / tpi, tt = blockIdx.x % tpi;
+  const int y0 = (tt / tpx) * TS, x0 = (tt % tpx) * TS;
+
+  bf16x8 bf[5][KH], af[MTW][KH];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) {
+    const int mt = wid + 4 * i, q = mt * 16 + r;
+    const int sy = y0 - 1 + q / HS, sx = x0 - 1 + q % HS;
+    const bool ok = q < NQ && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+#pragma unroll
+    for (int kh = 0; kh < KH; ++kh)
+      af[i][kh] = ok ? *reinterpret_cast<const bf16x8*>(src16 + ((long long)(n * H + sy) * W + sx) * C + kh * 32 + g * 8) : zero8();
+  }
+  load_bfrags<C>(w, lane, bf);
+
+  const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
+  float acc[4][3];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { acc[k][0] = 0.f; acc[k][1] = 0.f; acc[k][2] = 0.f; }
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky) {
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      const int mt = wid + 4 * i;
+      if (mt < NMT) {
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kh], bf[ky][kh], c, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sP[(mt * 16 + 4 * g + e) * PR + r] = c[e];
+      }
+    }
+    __syncthreads();
+    // out[2q+p] += src[q + d] W[k],  p = 1 - (k & 1),  d = (p + 1 - k) / 2   (conv2d_backprop_input, SAME, s=2, k=5)
+    const int py = 1 - (ky & 1), dy = (py + 1 - ky) / 2;
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) {
+      const int px = 1 - (kx & 1), dx = (px + 1 - kx) / 2;
+      const float* pp = sP + ((ly + 1 + dy) * HS + (lx + 1 + dx)) * PR + kx * 3;
+      acc[py * 2 + px][0] += pp[0]; acc[py * 2 + px][1] += pp[1]; acc[py * 2 + px][2] += pp[2];
+    }
+    __syncthreads();
+  }
+  const int yq = y0 + ly, xq = x0 + lx;
+#pragma unroll
+  for (int py = 0; py < 2; ++py) {
+    float* o = out + ((long long)(n * 2 * H + 2 * yq + py) * 2 * W + 2 * xq) * 3;
+#pragma unroll
+    for (int px = 0; px < 2; ++px)
+#pragma unroll
+      for (int co = 0; co < 3; ++co) o[px * 3 + co] = acc[py * 2 + px][co];
+  }
+}
+
+}  // namespace
+
+// ---- entry points (LG_ERR_UNSUPPORTED -> the caller falls back to the fp32-source kernels) ----
+extern "C" int lg_n3_p16_supported(int H, int W, int C) { return (H % TS == 0 && W % TS == 0 && (C == 32 || C == 64)) ? 1 : 0; }
+
+extern "C" int lg_n3_s1t_fwd_p16_try(const void* x16, const float* w, const float* bias, float* y, int B, int H, int W,
+                                     int C, void* stream) {
+  if (!lg_n3_p16_supported(H, W, C) || !x16 || !w || !bias) return LG_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(B * (H / TS) * (W / TS));
+  if (C == 32) hipLaunchKernelGGL(s1t_fwd_p16_kernel<32>, grid, dim3(256), 0, st, (const __bf16*)x16, w, bias, y, B, H, W);
+  else hipLaunchKernelGGL(s1t_fwd_p16_kernel<64>, grid, dim3(256), 0, st, (const __bf16*)x16, w, bias, y, B, H, W);
+  LG_CHECK_LAUNCH("lg_n3_s1t_fwd_p16");
+  return LG_OK;
+}
+
+extern "C" int lg_n3_up_p16_try(const void* src16, const float* w, float* out, int B, int H, int W, int C, void* stream) {
+  if (!lg_n3_p16_supported(H, W, C) || !src16 || !w) return LG_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(B * (H / TS) * (W / TS));
+  if (C == 32) hipLaunchKernelGGL(up_p16_kernel<32>, grid, dim3(256), 0, st, (const __bf16*)src16, w, out, B, H, W);
+  else hipLaunchKernelGGL(up_p16_kernel<64>, grid, dim3(256), 0, st, (const __bf16*)src16, w, out, B, H, W);
+  LG_CHECK_LAUNCH("lg_n3_up_p16");
+  return LG_OK;
+}

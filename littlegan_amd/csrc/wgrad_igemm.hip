@@ -327,8 +327,8 @@ inline int pick_nsplit(int tiles, int M, int KP) {
 }  // namespace
 
 extern "C" size_t lg_n3_wgrad_workspace_bytes(int B, int H, int W, int Cs);
-extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, float* dw, void* workspace, size_t ws_bytes, int B,
-                               int H, int W, int Cs, int s, int pad, int accumulate, void* stream);
+extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void* small16, float* dw, void* workspace,
+                               size_t ws_bytes, int B, int H, int W, int Cs, int s, int pad, int accumulate, void* stream);
 static size_t wgrad_ws_generic(int B, int Hm, int Wm, int cb, int cs, int dtype);
 
 extern "C" size_t lg_wgrad_workspace_bytes(int B, int Hm, int Wm, int cb, int cs, int dtype) {
@@ -364,15 +364,19 @@ extern "C" int lg_conv_wgrad(const float* big, const float* small, float* dw, vo
 extern "C" int lg_conv_wgrad_m16(const float* big, const void* big16, const float* small, const void* small16, float* dw,
                                  void* workspace, size_t ws_bytes, int B, int Hm, int Wm, int cb, int cs, int pstride,
                                  int ppad, int accumulate, int dtype, void* stream) {
-  LG_CHECK_ARG(dw && workspace && ((big && small) || (big16 && small16 && dtype == LG_DT_BF16 && cb != 3)),
-               "lg_conv_wgrad: null pointer (fp32 operands may be omitted only when both bf16 mirrors are given)");
+  LG_CHECK_ARG(dw && workspace && ((big && small) || (big16 && small16 && dtype == LG_DT_BF16 && cb != 3) ||
+                                   (cb == 3 && big && small16 && dtype == LG_DT_BF16)),
+               "lg_conv_wgrad: null pointer (fp32 operands may be omitted only when both bf16 mirrors are given; "
+               "3-channel layers: the bf16 mirror of `small` alone)");
   LG_CHECK_ARG(B > 0 && Hm > 0 && Wm > 0 && cs % 32 == 0 && (cb == 3 || cb % 32 == 0),
                "lg_conv_wgrad: bad shape B=%d Hm=%d Wm=%d cb=%d cs=%d", B, Hm, Wm, cb, cs);
   LG_CHECK_ARG(ws_bytes >= lg_wgrad_workspace_bytes(B, Hm, Wm, cb, cs, dtype), "lg_conv_wgrad: workspace too small");
   if (cb == 3 && !getenv("LG_NO_N3")) {  // all-taps 3-channel kernel (n3_kernels.hip) where its tiling applies
-    const int rc = lg_n3_wgrad_try(big, small, dw, workspace, ws_bytes, B, Hm, Wm, cs, pstride, ppad, accumulate, stream);
+    const int rc = lg_n3_wgrad_try(big, small, dtype == LG_DT_BF16 ? small16 : nullptr, dw, workspace, ws_bytes, B, Hm, Wm,
+                                   cs, pstride, ppad, accumulate, stream);
     if (rc != LG_ERR_UNSUPPORTED) return rc;
   }
+  LG_CHECK_ARG((big && small) || (cb != 3 && big16 && small16), "lg_conv_wgrad: this shape needs the fp32 operands");
   const bool patch = cb == 3;
   const bool bf16 = dtype == LG_DT_BF16 && !patch;  // patch layers stay on the exact f32 MFMA
   const int KP = bf16 ? 64 : 32;

@@ -168,12 +168,18 @@ class Encoder(_ConvStack):
                 x16 = x16[rows] if x16 is not None else None
             dgm = self._g[f"norm{i}.gamma"] if need_wgrad else None
             dbt = self._g[f"norm{i}.beta"] if need_wgrad else None
-            dz16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if (self.dtype == DT_BF16 and cb != 3) else None
             want_dx = i > 1 or need_input_grad
-            # the fp32 copy of dz is dead when every consumer reads the bf16 mirror: the data-gradient conv (halo kernel),
-            # the weight-gradient kernel (needs the mirror of x too) and the bias column sums
-            drop32 = (dz16 is not None and (not need_wgrad or x16 is not None) and
-                      (not want_dx or ops.conv_halo_supported(1, self.dtype, z.shape[0], z.shape[1], z.shape[2], cs, cb)))
+            m16 = self.dtype == DT_BF16
+            # the fp32 copy of dz is dead when every consumer reads the bf16 mirror: the data-gradient conv (halo kernel,
+            # or the tap-product kernel of the 3-channel level 1), the weight-gradient kernel (needs the mirror of x too;
+            # level 1: reads the fp32 image and the mirror of dz) and the bias column sums
+            if cb != 3:
+                dz16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if m16 else None
+                drop32 = (m16 and (not need_wgrad or x16 is not None) and
+                          (not want_dx or ops.conv_halo_supported(1, self.dtype, z.shape[0], z.shape[1], z.shape[2], cs, cb)))
+            else:
+                drop32 = m16 and ops.n3_m16_supported(z.shape[1], z.shape[2], cb, cs, self.dtype)
+                dz16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if drop32 else None
             dz = ops.instnorm_bwd(z, st, g_h, dgm, dbt, 0, 1, a, out16=dz16, want_f32=not drop32)
             if need_wgrad:
                 ops.conv2d_s2_wgrad(x, dz, self._g[f"conv{i}.kernel"], False, self.dtype, x16=x16, dy16=dz16)
@@ -187,7 +193,8 @@ class Encoder(_ConvStack):
 
 class Decoder(_ConvStack):
     """model.py:30-51.  conv_i: Conv2DTranspose(conv_filter[i], 5, (2,2), 'same') -> InstanceNorm -> leaky,
-    with `x += add[i-1]` in front of every level whose skip is not None."""
+    with `x += add[i-1]` in front of every level whose skip is not None.
+    Returns (x, x16): the fp32 output and/or its bf16 mirror (bf16 path: possibly only the mirror)."""
 
     def __init__(self, args):
         cf = args.conv_filter
@@ -212,19 +219,25 @@ class Decoder(_ConvStack):
             if st is None:
                 st = ops.instnorm_stats(z, gm, bt, 0, a)
             skip = add[i] if i < 4 else None
-            h16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if (m16 and i < 4) else None
-            # levels 1-3 feed only the next transposed conv and its weight gradient: both read the bf16 mirror
-            drop32 = (h16 is not None and ops.conv_halo_supported(1, self.dtype, z.shape[0], z.shape[1], z.shape[2], cb,
-                                                                  self.chans[i][0]))
+            # levels 1-3 feed only the next transposed conv and its weight gradient, level 4 the final 3-channel
+            # layer: where those kernels read the bf16 mirror, the fp32 copy is not written at all
+            if i < 4:
+                drop32 = m16 and ops.conv_halo_supported(1, self.dtype, z.shape[0], z.shape[1], z.shape[2], cb,
+                                                         self.chans[i][0])
+                want16 = m16
+            else:
+                drop32 = want16 = m16 and ops.n3_m16_supported(z.shape[1], z.shape[2], self.args.image_channel, cb,
+                                                               self.dtype)
+            h16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if want16 else None
             h = ops.instnorm_apply(z, st, skip, 0, 1, a, out16=h16, want_f32=not drop32)
             saved.append((x, z, st, x16))
             x, x16 = h, h16
         if ctx is not None:
             ctx["dec"] = saved
-        return x
+        return x, x16
 
     def backward(self, ctx, g_h, need_wgrad: bool):
-        """Returns the gradient w.r.t. the decoder input x (skip tensors receive the same gradient as the
+        """g_h: fp32 or (bf16 path) bf16.  Returns the gradient w.r.t. the decoder input x (skip tensors receive the same gradient as the
         level input they were added to; no tape of the step asks for it)."""
         a = self.args.leaky_alpha
         packs = self.packs()
@@ -262,15 +275,18 @@ class _FinalConv(_Module):
             self._pack_version = self.version
         return self._pack
 
-    def __call__(self, x, out=None):
-        return ops.convT_s1_tanh_fwd(x, self.pack(), self._w["bias"], self.cb, self.dtype, out=out)
+    def __call__(self, x, out=None, x16=None):
+        return ops.convT_s1_tanh_fwd(x, self.pack(), self._w["bias"], self.cb, self.dtype, out=out, x16=x16)
 
-    def backward(self, x, dpre, need_wgrad: bool):
+    def backward(self, x, dpre, need_wgrad: bool, x16=None):
+        """Returns dL/dx: fp32, or bf16 in the bf16 path (the decoder's norm backward reads either)."""
         B, H, W, _ = dpre.shape
-        dx = torch.empty(B, H, W, self.cs, dtype=torch.float32, device=dpre.device)
-        ops.convT_s1_tanh_bwd(x if need_wgrad else None, dpre, self.pack(), self.cs, self.dtype, dx=dx,
+        g16 = self.dtype == DT_BF16
+        dx = torch.empty(B, H, W, self.cs, dtype=torch.bfloat16 if g16 else torch.float32, device=dpre.device)
+        ops.convT_s1_tanh_bwd(x if need_wgrad else None, dpre, self.pack(), self.cs, self.dtype,
+                              dx=None if g16 else dx, dx16=dx if g16 else None,
                               dw=self._g["kernel"] if need_wgrad else None,
-                              db=self._g["bias"] if need_wgrad else None)
+                              db=self._g["bias"] if need_wgrad else None, x16=x16 if need_wgrad else None)
         return dx
 
 
@@ -332,15 +348,15 @@ class Generator(_Module):
         noise, cond = inputs
         x0 = torch.cat([noise, cond], dim=-1).contiguous()
         w4 = self._dn(x0, ctx)
-        xdec = self.decoder([w4, [None] * 4], ctx)
-        img = self.conv(xdec, out=out)
+        xdec, xdec16 = self.decoder([w4, [None] * 4], ctx)
+        img = self.conv(xdec, out=out, x16=xdec16)
         if ctx is not None:
-            ctx["xdec"], ctx["img"] = xdec, img
+            ctx["xdec"], ctx["xdec16"], ctx["img"] = xdec, xdec16, img
         return img
 
     def backward(self, ctx, dpre):
         """dpre = dL/d(pre-tanh image).  Writes all 22 weight gradients."""
-        g = self.conv.backward(ctx["xdec"], dpre, need_wgrad=True)
+        g = self.conv.backward(ctx["xdec"], dpre, need_wgrad=True, x16=ctx.get("xdec16"))
         g = self.decoder.backward(ctx, g, need_wgrad=True)
         self._dn.backward(ctx, g)
 
@@ -421,10 +437,10 @@ class Adjuster(_Module):
         else:  # the trailing samples of `image` were already encoded by D in this step (same weights): reuse
             enc = self.encoder(image[:image.shape[0] - enc_tails[0].shape[0]], None, tails=enc_tails)
         c4 = self._dn(cond.contiguous(), ctx)
-        x = self.decoder([c4, enc[::-1]], ctx)
-        img = self.conv(x)
+        x, x16 = self.decoder([c4, enc[::-1]], ctx)
+        img = self.conv(x, x16=x16)
         if ctx is not None:
-            ctx["xdec"], ctx["img"] = x, img
+            ctx["xdec"], ctx["xdec16"], ctx["img"] = x, x16, img
         return img
 
     def backward_own(self, ctx, dpre):

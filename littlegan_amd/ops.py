@@ -142,12 +142,16 @@ def _wgrad(fn_name, big, small, dw, accumulate, dtype, swap, big16=None, small16
         _chk(big, (B, 2 * Hs, 2 * Ws, cb), "big")
     if small is not None:
         _chk(small, name="small")
-    if (big is None or small is None) and (big16 is None or small16 is None):
+    n3 = cb == 3 and big is not None and small16 is not None  # 3-channel layer: fp32 image + mirror of the wide operand
+    if (big is None or small is None) and (big16 is None or small16 is None) and not n3:
         raise ValueError("wgrad: an fp32 operand may be omitted only when BOTH bf16 mirrors are given")
     _chk(dw, (5, 5, cb, cs), "dw")
     nbytes = int(lib.lg_wgrad_workspace_bytes(B, Hs, Ws, cb, cs, dtype))
     ws = workspace(nbytes, dw.device, "wgrad")
-    if big16 is None or small16 is None:
+    if n3:
+        big16 = None
+        _chk16(small16, small if small is not None else small16, "small16")
+    elif big16 is None or small16 is None:
         big16 = small16 = None  # the bf16-source kernel needs both mirrors
     else:
         _chk16(big16, big if big is not None else big16, "big16")
@@ -207,37 +211,55 @@ def convT_s2_wgrad(x, dy, dw, accumulate, dtype, x16=None, dy16=None):
     return _wgrad("lg_convT_s2_wgrad_m16", dy, x, dw, accumulate, dtype, swap=True, big16=dy16, small16=x16)
 
 
-def convT_s1_tanh_fwd(x, pack, bias, cb, dtype, out=None):
-    B, H, W, cs = x.shape
-    _chk(x, name="x")
+def n3_m16_supported(H, W, cb, cs, dtype):
+    """bf16 path: the 3-channel layers of this shape read the bf16 mirror of their wide operand alone."""
+    return bool(_lib.load().lg_n3_m16_supported(H, W, cb, cs, dtype))
+
+
+def convT_s1_tanh_fwd(x, pack, bias, cb, dtype, out=None, x16=None):
+    """x16: bf16 mirror of x (bf16 path); x may be None where n3_m16_supported."""
+    t = x if x is not None else x16
+    B, H, W, cs = t.shape
+    if x is not None:
+        _chk(x, name="x")
+    if x16 is not None:
+        _chk16(x16, t, "x16")
     if out is None:
-        out = torch.empty(B, H, W, cb, dtype=torch.float32, device=x.device)
+        out = torch.empty(B, H, W, cb, dtype=torch.float32, device=t.device)
     _chk(out, (B, H, W, cb), "out")
     _chk(bias, (cb,), "bias")
     e0 = _pb()
-    check(_lib.load().lg_convT_s1_tanh_fwd(_p(x), _p(pack), _p(bias), _p(out), B, H, W, cb, cs, dtype, _stream()),
-          "lg_convT_s1_tanh_fwd")
+    check(_lib.load().lg_convT_s1_tanh_fwd_m16(_p(x), _p(x16), _p(pack), _p(bias), _p(out), B, H, W, cb, cs, dtype,
+                                               _stream()), "lg_convT_s1_tanh_fwd_m16")
     _pe(e0, "conv_igemm_s1t_n3", 50.0 * B * H * W * cb * cs)
     return out
 
 
-def convT_s1_tanh_bwd(x, dpre, pack, cs, dtype, dx=None, dw=None, db=None, accumulate=False):
+def convT_s1_tanh_bwd(x, dpre, pack, cs, dtype, dx=None, dw=None, db=None, accumulate=False, x16=None, dx16=None):
+    """x16: bf16 mirror of x for the weight gradient; dx16: bf16 tensor that receives the data gradient instead of dx."""
     lib = _lib.load()
     B, H, W, cb = dpre.shape
     _chk(dpre, name="dpre")
     if x is not None:
         _chk(x, (B, H, W, cs), "x")
+    if x16 is not None:
+        if x16.dtype != torch.bfloat16 or tuple(x16.shape) != (B, H, W, cs) or not x16.is_contiguous():
+            raise ValueError("convT_s1_tanh_bwd: x16 must be a contiguous bf16 [B,H,W,cs] tensor")
     if dx is not None:
         _chk(dx, (B, H, W, cs), "dx")
+    if dx16 is not None:
+        if dx16.dtype != torch.bfloat16 or tuple(dx16.shape) != (B, H, W, cs) or not dx16.is_contiguous():
+            raise ValueError("convT_s1_tanh_bwd: dx16 must be a contiguous bf16 [B,H,W,cs] tensor")
     if dw is not None:
         _chk(dw, (5, 5, cb, cs), "dw")
     if db is not None:
         _chk(db, (cb,), "db")
     nbytes = int(lib.lg_convT_s1_bwd_workspace_bytes(B, H, W, cb, cs, dtype))
     ws = workspace(nbytes, dpre.device, "wgrad")
-    check(lib.lg_convT_s1_tanh_bwd(_p(x), _p(dpre), _p(pack), _p(dx), _p(dw), _p(db), _p(ws), ws.numel(), B, H, W, cb,
-                                   cs, int(accumulate), dtype, _stream()), "lg_convT_s1_tanh_bwd")
-    return dx
+    check(lib.lg_convT_s1_tanh_bwd_m16(_p(x), _p(x16), _p(dpre), _p(pack), _p(dx), _p(dx16), _p(dw), _p(db), _p(ws),
+                                       ws.numel(), B, H, W, cb, cs, int(accumulate), dtype, _stream()),
+          "lg_convT_s1_tanh_bwd_m16")
+    return dx if dx is not None else dx16
 
 
 def bias_grad(dy, db, accumulate=False, dy16=None):

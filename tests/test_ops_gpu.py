@@ -310,3 +310,66 @@ def test_norm_kernels_write_bf16_mirrors(ops):
     d16 = torch.empty(x.shape, dtype=torch.bfloat16, device="cuda")
     d = ops.instnorm_bwd(x, st, g, None, None, 0, 1, 0.3, out16=d16)
     assert torch.equal(d16, d.to(torch.bfloat16))
+
+
+def _bf16_round(a):
+    """the values a bf16 RNE rounding of the fp32 array keeps, as float64"""
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32).to(torch.bfloat16).double().numpy()
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 32), (1, 32, 48, 32), (2, 16, 32, 64)])
+def test_n3_tap_product_kernels_from_bf16_mirror(ops, case):
+    """bf16 path of the 3-channel layers (n3_pgemm.hip): they read ONLY the bf16 mirror of the wide operand and the
+    pack's fp32 weights rounded to bf16; products are exact and accumulate in fp32, so against the oracle on the SAME
+    rounded operands the error is an fp32-accumulation error, not a bf16 one."""
+    B, H, W, C = case
+    rng = np.random.default_rng(zlib_crc(case))
+    x = r32(rng, B, H, W, C)
+    w = r32(rng, 5, 5, 3, C, scale=0.05)
+    b = r32(rng, 3, scale=0.1)
+    dpre = r32(rng, B, H, W, 3)
+    assert ops.n3_m16_supported(H, W, 3, C, 1) and not ops.n3_m16_supported(H, W, 3, C, 0)
+    assert not ops.n3_m16_supported(H + 2, W, 3, C, 1)
+    pack = ops.conv_pack(dev(w), 3, C, 1)
+    x16 = dev(x).to(torch.bfloat16)
+    xr, wr = _bf16_round(x), _bf16_round(w)
+    # final layer forward: tanh(convT_s1(x) + b), x given as mirror only
+    y = ops.convT_s1_tanh_fwd(None, pack, dev(b), 3, 1, x16=x16)
+    assert rel(y, np.tanh(O.conv2d_transpose(xr, wr, b, 1))) < 3e-5
+    # final layer backward: weight gradient from the mirror, data gradient written as bf16
+    dx_e, dw_e, db_e = O.conv2d_transpose_bwd(xr, w, dpre, 1)
+    dx16 = torch.empty(B, H, W, C, dtype=torch.bfloat16, device="cuda")
+    dw = torch.empty(5, 5, 3, C, device="cuda")
+    db = torch.empty(3, device="cuda")
+    ops.convT_s1_tanh_bwd(None, dev(dpre), pack, C, 1, dx16=dx16, dw=dw, db=db, x16=x16)
+    assert rel(dw, dw_e) < 3e-5 and rel(db, db_e) < 3e-5
+    assert rel(dx16.float(), dx_e) < TOL[1]
+    # Encoder.conv1 gradients: dz [B,H,W,C] given as mirror only; image x3 [B,2H,2W,3] fp32
+    x3 = r32(rng, B, 2 * H, 2 * W, 3)
+    w1 = r32(rng, 5, 5, 3, C, scale=0.05)
+    dz = r32(rng, B, H, W, C)
+    pack1 = ops.conv_pack(dev(w1), 3, C, 1)
+    dz16 = dev(dz).to(torch.bfloat16)
+    dzr, w1r = _bf16_round(dz), _bf16_round(w1)
+    dimg = ops.conv2d_s2_dgrad(None, pack1, 3, 1, dy16=dz16)
+    assert rel(dimg, O.conv2d_bwd(x3, w1r, dzr, 2)[0]) < 3e-5
+    dw1 = torch.empty(5, 5, 3, C, device="cuda")
+    ops.conv2d_s2_wgrad(dev(x3), None, dw1, False, 1, dy16=dz16)
+    assert rel(dw1, O.conv2d_bwd(x3, w1, dzr, 2)[1]) < 3e-5
+
+
+def zlib_crc(case):
+    import zlib
+    return zlib.crc32(repr(case).encode())
+
+
+def test_norm_apply_mirror_only(ops):
+    rng = np.random.default_rng(4)
+    x = dev(r32(rng, 2, 8, 8, 32))
+    gm, bt = dev(np.array([0.9])), dev(np.array([-0.2]))
+    st = ops.instnorm_stats(x, gm, bt, 0, 0.3)
+    y16a = torch.empty(x.shape, dtype=torch.bfloat16, device="cuda")
+    y16b = torch.empty(x.shape, dtype=torch.bfloat16, device="cuda")
+    y = ops.instnorm_apply(x, st, None, 0, 1, 0.3, out16=y16a)
+    assert ops.instnorm_apply(x, st, None, 0, 1, 0.3, out16=y16b, want_f32=False) is None
+    assert torch.equal(y16a, y16b) and torch.equal(y16a, y.to(torch.bfloat16))
