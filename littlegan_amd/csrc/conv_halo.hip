@@ -36,6 +36,7 @@ struct HaloParams {
   double* spart;               // fused InstanceNorm moments: [B][nparts][3] = {count, mean, M2} per block, or null
   int nparts;
   int dry;                     // 1: only answer whether this kernel covers the shape (no launch)
+  int res_budget;              // LDS bytes the resident-halo (RES) variant may use; 0 = variant off
 };
 
 template <typename T> struct DT;
@@ -61,31 +62,36 @@ __device__ __forceinline__ void tap_info(int mode, int cls, int t, int& dy, int&
   }
 }
 
-template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, int WAVES_M, int WAVES_N, int MT, int NT>
+// RES ("resident"): UP mode from the bf16 mirror with the halo of ALL Cs channels staged once; the block then runs the
+// four parity classes one after the other out of that image (grid.y == 1): a quarter of the source traffic and no
+// barrier at all inside the (class, chunk, tap) loops.
+template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES, int WAVES_M, int WAVES_N, int MT, int NT>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
   static_assert(!SRC16 || (sizeof(T) == 2 && !DBUF), "bf16 source only with bf16 MFMA, single-buffered halo");
+  static_assert(!RES || (SRC16 && MODE == MODE_UP), "resident halo: UP mode from the bf16 mirror");
   constexpr int ESZ = DT<T>::ESZ;
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
   static_assert(BM == 128, "halo tiles are 128 rows");
-  constexpr int ROWB = KCH * 32 + 16;
   constexpr int KC = KCH * 32 / ESZ;
-  constexpr int LPR = SRC16 ? KC / 8 : KC / 4;  // threads per halo row (16 B each: 4 fp32 or 8 bf16 channels)
-  constexpr int RPP = 256 / LPR;     // halo rows per pass
+  const int ROWB = RES ? p.Cs * ESZ + 16 : KCH * 32 + 16;    // LDS bytes per halo row (RES: all channels)
+  const int LPR = RES ? p.Cs / 8 : (SRC16 ? KC / 8 : KC / 4);  // threads per halo row (16 B each: 4 fp32 or 8 bf16 channels)
+  const int RPP = 256 / LPR;         // halo rows per pass
   constexpr int SS = (MODE == MODE_DOWN) ? 2 : 1;
   constexpr int LO = (MODE == MODE_S1T) ? -2 : -1;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* s_out = reinterpret_cast<int*>(smem);          // [128]
-  int* s_hoff = s_out + BM;                           // [nrows] source pixel index or -1
-  char* sH = smem + ((BM + p.nrows) * 4 + 15) / 16 * 16;   // [DBUF ? 2 : 1][nrows][ROWB]
+  constexpr int NCLS = RES ? 4 : 1;
+  int* s_out = reinterpret_cast<int*>(smem);          // [NCLS][128] output pixel per M row (RES: per class)
+  int* s_hoff = s_out + NCLS * BM;                    // [nrows] source pixel index or -1
+  char* sH = smem + ((NCLS * BM + p.nrows) * 4 + 15) / 16 * 16;   // [DBUF ? 2 : 1][nrows][ROWB]
   const int HBYTES = p.nrows * ROWB;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  const int cls = (MODE == MODE_UP) ? (3 - (int)blockIdx.y) : 0;
-  const int py = cls >> 1, px = cls & 1;
+  int cls = (MODE == MODE_UP) ? (3 - (int)blockIdx.y) : 0;  // RES: set per pass of the class loop below
+  int py = cls >> 1, px = cls & 1;
   const int lb = lg_xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = lb % p.ntn, tile_m = lb / p.ntn;
   const int n0 = tile_n * BN;
@@ -106,13 +112,18 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
     const int i = tid / THW, rem = tid - i * THW;
     const int ly = rem / p.TW, lx = rem - ly * p.TW;
     const int n = img0 + i, y = y0 + ly, x = x0 + lx;
-    int o = -1;
-    if (n < p.B) {
-      const int oy = (MODE == MODE_UP) ? 2 * y + py : y;
-      const int ox = (MODE == MODE_UP) ? 2 * x + px : x;
-      o = (n * p.Ho + oy) * p.Wo + ox;
+    if constexpr (RES) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s_out[c * BM + tid] = n < p.B ? (n * p.Ho + 2 * y + (c >> 1)) * p.Wo + 2 * x + (c & 1) : -1;
+    } else {
+      int o = -1;
+      if (n < p.B) {
+        const int oy = (MODE == MODE_UP) ? 2 * y + py : y;
+        const int ox = (MODE == MODE_UP) ? 2 * x + px : x;
+        o = (n * p.Ho + oy) * p.Wo + ox;
+      }
+      s_out[tid] = o;
     }
-    s_out[tid] = o;
   }
   for (int hr = tid; hr < p.nrows; hr += 256) {
     const int i = hr / p.HROWS, rem = hr - i * p.HROWS;
@@ -139,18 +150,12 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
   const int nchunk = p.Cs / KC;
 
   f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int arow = tid / LPR, alc = tid % LPR;
   constexpr int NB = NT * KCH;  // B fragments (1 KiB each, 16 B per lane) of one tap for this wave's NT column tiles
   u32x4 fb0[NB], fb1[NB], fb2[NB];  // three register sets: fragments are fetched two taps ahead of their use
 
-  const int nit = nchunk * ntaps;  // flat (chunk, tap) iteration space
+  int nit = nchunk * ntaps;  // flat (chunk, tap) iteration space
   const int KB = p.Cs * ESZ / 32, N32 = p.Npad >> 5;
   const int nt0 = (n0 >> 5) + wn * NT;
 
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
   auto stage_halo = [&](int c0, char* sH) {  // synchronous: up to SU halo rows in flight per thread (one L2/HBM latency
     constexpr int SU = 12;                   // per SU*RPP rows instead of one per 4*RPP)
     for (int hr0 = 0; hr0 < p.nrows; hr0 += SU * RPP) {
-      if constexpr (SRC16) {  // bf16 mirror: 16 B = 8 channels, straight into the LDS image (no conversion)
+      if constexpr (SRC16) {  // bf16 mirror: 16 B = 8 channels, straight into the LDS image (no conversion); RES: c0 == 0
         u32x4 v[SU];
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
@@ -215,10 +220,11 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
     }
   };
   auto compute = [&](int it, const u32x4 (&fb)[NB], const char* sH) {
-    const int t = it % ntaps;
+    const int cc = it / ntaps, t = it - cc * ntaps;
     int dy, dx, widx;
     tap_info(MODE, cls, t, dy, dx, widx);
     const int toff = dy * p.HW + dx;
+    if constexpr (RES) sH += cc * (KCH * 32);  // this chunk's channels inside the resident row
 #pragma unroll
     for (int q = 0; q < KCH; ++q) {
       if constexpr (ESZ == 4) {
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
     }
     if (!(p.dbg & 1)) compute(it, cur, hcur);
     if (it + 3 < nit && !(p.dbg & 2)) load_frags(cur, it + 3);
-    if (t + 1 == ntaps && it + 1 < nit && !(p.dbg & 4)) {
+    if (!RES && t + 1 == ntaps && it + 1 < nit && !(p.dbg & 4)) {
       __syncthreads();
       if constexpr (DBUF) {
         hsel ^= 1;
@@ -311,97 +317,121 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
   };
 
   __syncthreads();  // tables visible
-  load_frags(fb0, 0);
-  if (nit > 1) load_frags(fb1, 1);
-  if (nit > 2) load_frags(fb2, 2);
-  stage_halo(0, sH);
-  __syncthreads();
-  for (int it = 0; it < nit; it += 3) {
-    iteration(it, fb0);
-    if (it + 1 < nit) iteration(it + 1, fb1);
-    if (it + 2 < nit) iteration(it + 2, fb2);
+  if constexpr (RES) {
+    stage_halo(0, sH);
+    __syncthreads();
   }
+  double* sred = reinterpret_cast<double*>(RES ? s_hoff : s_out);  // reduction scratch of the moments epilogue (16-B aligned)
+#pragma unroll 1
+  for (int pass = 0; pass < NCLS; ++pass) {
+    if constexpr (RES) {
+      cls = 3 - pass; py = cls >> 1; px = cls & 1;
+      ntaps = (py ? 3 : 2) * (px ? 3 : 2);
+      if (p.dbg & 8) ntaps = 1;
+      nit = nchunk * ntaps;
+    }
+    const int* so = s_out + (RES ? cls * BM : 0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    load_frags(fb0, 0);
+    if (nit > 1) load_frags(fb1, 1);
+    if (nit > 2) load_frags(fb2, 2);
+    if constexpr (!RES) {
+      stage_halo(0, sH);
+      __syncthreads();
+    }
+    for (int it = 0; it < nit; it += 3) {
+      iteration(it, fb0);
+      if (it + 1 < nit) iteration(it + 1, fb1);
+      if (it + 2 < nit) iteration(it + 2, fb2);
+    }
 
-  // ---- epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----------
+    // ---- epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----------
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = n0 + (wn * NT + j) * 32 + r;
-    const bool cok = col < p.N;
-    const float bv = (cok && p.bias) ? p.bias[col] : 0.f;
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + (wn * NT + j) * 32 + r;
+      const bool cok = col < p.N;
+      const float bv = (cok && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+      for (int i = 0; i < MT; ++i) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int o = s_out[row];
-        if (cok && o >= 0) {
-          float v = acc[i][j][e] + bv;
-          if (p.act == 1) v = tanhf(v);
-          if (p.out16) p.out16[(long long)o * p.N + col] = (__bf16)v;
-          else p.out[(long long)o * p.N + col] = v;
+        for (int e = 0; e < 16; ++e) {
+          const int row = (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int o = so[row];
+          if (cok && o >= 0) {
+            float v = acc[i][j][e] + bv;
+            if (p.act == 1) v = tanhf(v);
+            if (p.out16) p.out16[(long long)o * p.N + col] = (__bf16)v;
+            else p.out[(long long)o * p.N + col] = v;
+          }
         }
       }
     }
-  }
 
-  // ---- fused InstanceNormalization moments of this block's output tile (one sample per block: NI == 1) ----------
-  // {count, mean, M2 about the block mean}, merged per sample with Chan's formula by stats_final_kernel (norm.hip):
-  // the separate pass that re-read the whole conv output for its moments is gone.
-  if (p.spart) {
-    float s = 0.f;
+    // ---- fused InstanceNormalization moments of this block's output tile (one sample per block: NI == 1) ----------
+    // {count, mean, M2 about the block mean}, merged per sample with Chan's formula by stats_final_kernel (norm.hip):
+    // the separate pass that re-read the whole conv output for its moments is gone.
+    if (p.spart) {
+      float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = n0 + (wn * NT + j) * 32 + r;
-      if (col < p.N) {
-        const float bv = p.bias ? p.bias[col] : 0.f;
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + (wn * NT + j) * 32 + r;
+        if (col < p.N) {
+          const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) s += acc[i][j][e] + bv;
+            for (int e = 0; e < 16; ++e) s += acc[i][j][e] + bv;
+        }
       }
-    }
-    __syncthreads();  // s_out is dead from here on: reuse it as reduction scratch (16-B aligned)
-    double* sred = reinterpret_cast<double*>(s_out);
-    const int ncol = min(BN, p.N - n0);
-    const double cnt = 128.0 * (double)ncol;
-    double red[1] = {(double)s};
-    lg_block_sum_d<1>(red, sred);
-    if (tid == 0) sred[16] = red[0] / cnt;
-    __syncthreads();
-    const float mean = (float)sred[16];
-    float m2 = 0.f;
+      __syncthreads();  // the scratch (s_out, or s_hoff under RES) is dead from here on for its first use
+      const int ncol = min(BN, p.N - n0);
+      const double cnt = 128.0 * (double)ncol;
+      double red[1] = {(double)s};
+      lg_block_sum_d<1>(red, sred);
+      if (tid == 0) sred[16] = red[0] / cnt;
+      __syncthreads();
+      const float mean = (float)sred[16];
+      float m2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = n0 + (wn * NT + j) * 32 + r;
-      if (col < p.N) {
-        const float bv = p.bias ? p.bias[col] : 0.f;
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + (wn * NT + j) * 32 + r;
+        if (col < p.N) {
+          const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) { const float d = (acc[i][j][e] + bv) - mean; m2 += d * d; }
+            for (int e = 0; e < 16; ++e) { const float d = (acc[i][j][e] + bv) - mean; m2 += d * d; }
+        }
       }
-    }
-    const double meand = sred[16];
-    double red2[1] = {(double)m2};
-    lg_block_sum_d<1>(red2, sred);
-    if (tid == 0) {
-      const int tin = tile_m - img0 * p.tpi;  // tile within the image
-      const int part = (cls * p.tpi + tin) * p.ntn + tile_n;
-      double* o = p.spart + ((long long)img0 * p.nparts + part) * 3;
-      // M2 was taken about the float-rounded mean: shift it to the exact block mean (M2' = M2 - cnt*(mean_f - mean)^2)
-      const double df = (double)mean - meand;
-      o[0] = cnt; o[1] = meand; o[2] = red2[0] - cnt * df * df;
+      const double meand = sred[16];
+      double red2[1] = {(double)m2};
+      lg_block_sum_d<1>(red2, sred);
+      if (tid == 0) {
+        const int tin = tile_m - img0 * p.tpi;  // tile within the image
+        const int part = (cls * p.tpi + tin) * p.ntn + tile_n;
+        double* o = p.spart + ((long long)img0 * p.nparts + part) * 3;
+        // M2 was taken about the float-rounded mean: shift it to the exact block mean (M2' = M2 - cnt*(mean_f - mean)^2)
+        const double df = (double)mean - meand;
+        o[0] = cnt; o[1] = meand; o[2] = red2[0] - cnt * df * df;
+      }
+      if constexpr (RES) __syncthreads();  // scratch reused by the next class
     }
   }
 }
 
 constexpr int LDS_BUDGET = 80 * 1024;  // two blocks per CU (160 KiB)
 
-template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, int WAVES_M, int WAVES_N, int MT, int NT>
+template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES, int WAVES_M, int WAVES_N, int MT, int NT>
 int launch(HaloParams p, hipStream_t st) {
-  constexpr int BN = WAVES_N * NT * 32, ROWB = KCH * 32 + 16;
-  const size_t lds = ((128 + p.nrows) * 4 + 15) / 16 * 16 + (size_t)p.nrows * ROWB * (DBUF ? 2 : 1);
-  if (lds > LDS_BUDGET) return LG_ERR_UNSUPPORTED;
+  constexpr int BN = WAVES_N * NT * 32;
+  const int ROWB = RES ? p.Cs * DT<T>::ESZ + 16 : KCH * 32 + 16;
+  const size_t lds = (((RES ? 4 : 1) * 128 + p.nrows) * 4 + 15) / 16 * 16 + (size_t)p.nrows * ROWB * (DBUF ? 2 : 1);
+  if (lds > (size_t)(RES ? p.res_budget : LDS_BUDGET)) return LG_ERR_UNSUPPORTED;
   if (DBUF) {  // the interleaved prefetch must fit its register window: ceil(NU/(ntaps-1)) <= 4 with the fewest taps
     constexpr int KC = KCH * 32 / DT<T>::ESZ, RPP = 256 / (SRC16 ? KC / 8 : KC / 4);
     const int NU = (p.nrows + RPP - 1) / RPP, min_taps = MODE == MODE_UP ? 4 : 25;
@@ -410,11 +440,11 @@ int launch(HaloParams p, hipStream_t st) {
   p.ntn = p.Npad / BN;
   p.nparts = (MODE == MODE_UP ? 4 : 1) * p.tpi * p.ntn;
   const int ntm = p.NI == 1 ? p.B * p.tpi : lg_cdiv(p.B, p.NI);
-  dim3 grid(ntm * p.ntn, MODE == MODE_UP ? 4 : 1);
-  auto kern = conv_halo_kernel<T, MODE, KCH, DBUF, SRC16, WAVES_M, WAVES_N, MT, NT>;
+  dim3 grid(ntm * p.ntn, (MODE == MODE_UP && !RES) ? 4 : 1);
+  auto kern = conv_halo_kernel<T, MODE, KCH, DBUF, SRC16, RES, WAVES_M, WAVES_N, MT, NT>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RES ? 160 * 1024 : LDS_BUDGET);
     attr_set = true;
   }
   if (p.dry) return LG_OK;
@@ -422,17 +452,25 @@ int launch(HaloParams p, hipStream_t st) {
   return LG_OK;
 }
 
-template <typename T, int MODE, int KCH, bool DBUF, bool SRC16>
+template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES = false>
 int dispatch_bn2(const HaloParams& p, hipStream_t st) {
-  if (p.Npad % 128 == 0) return launch<T, MODE, KCH, DBUF, SRC16, 2, 2, 2, 2>(p, st);
-  if (p.Npad % 64 == 0) return launch<T, MODE, KCH, DBUF, SRC16, 2, 2, 2, 1>(p, st);
-  return launch<T, MODE, KCH, DBUF, SRC16, 4, 1, 1, 1>(p, st);
+  if (p.Npad % 128 == 0) return launch<T, MODE, KCH, DBUF, SRC16, RES, 2, 2, 2, 2>(p, st);
+  if (p.Npad % 64 == 0) return launch<T, MODE, KCH, DBUF, SRC16, RES, 2, 2, 2, 1>(p, st);
+  return launch<T, MODE, KCH, DBUF, SRC16, RES, 4, 1, 1, 1>(p, st);
 }
 template <typename T, int MODE, int KCH>
 int dispatch_bn(const HaloParams& p, hipStream_t st) {
   int rc = LG_ERR_UNSUPPORTED;
   if constexpr (sizeof(T) == 2) {
-    if (p.src16) return dispatch_bn2<T, MODE, KCH, false, true>(p, st);  // bf16 mirror of the source available
+    if (p.src16) {  // bf16 mirror of the source available
+      if constexpr (MODE == MODE_UP && KCH == 4) {  // all channels resident, the four classes in one block
+        if (p.res_budget > 0) {
+          const int rc = dispatch_bn2<T, MODE, KCH, false, true, true>(p, st);
+          if (rc != LG_ERR_UNSUPPORTED) return rc;
+        }
+      }
+      return dispatch_bn2<T, MODE, KCH, false, true>(p, st);
+    }
   }
   if ((p.dbg & 64) && p.Cs / (KCH * 32 / DT<T>::ESZ) > 1) rc = dispatch_bn2<T, MODE, KCH, true, false>(p, st);  // double-buffered halo: measured slower, opt-in
   if (rc == LG_ERR_UNSUPPORTED) rc = dispatch_bn2<T, MODE, KCH, false, false>(p, st);
@@ -486,6 +524,9 @@ extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const voi
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("LG_DBG"); dbg = e ? atoi(e) : 0; }
     p.dbg = dbg;
+    static int resb = -1;  // LG_RES_KB: LDS budget (KiB) of the resident-halo UP variant; 0 switches it off (A/B)
+    if (resb < 0) { const char* e = getenv("LG_RES_KB"); resb = (e ? atoi(e) : 52) * 1024; }
+    p.res_budget = resb;
   }
   int nparts = 0;
   if (spart && nparts_out && p.NI == 1 && act == 0) {
