@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void n3_up_kernel(const float* __restrict__ sr
 // weight gradient of a 3-channel layer, all 25 taps at once.  GEMM: M = 75 (tap, c3) -> 3 MFMA row tiles,
 // N = Cs (1 or 2 column tiles), K = pixels of the small grid.  A[i][k] is GATHERED from an LDS halo of the
 // 3-channel tensor (per-lane row offset + per-k pixel base), B[k][j] is the small tensor's pixel row.
-// Block = 4 waves, pixel tile 8x16: wave w reduces pixels [32w, 32w+32) and writes its own fp32 slab.
+// Block = 4 waves, pixel tile 8x16: wave w reduces pixels [32w, 32w+32); the waves merge into one fp32 slab per block.
 // --------------------------------------------------------------------------------------------------------------
 // S16: `small` is read from its bf16 mirror (bf16 path; the values are widened exactly, the MFMA stays f32).
 template <int NT, bool S16>
@@ -193,31 +193,53 @@ __global__ __launch_bounds__(256) void n3_wgrad_kernel(const float* __restrict__
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
-  float* o = slab + (long long)(blockIdx.x * 4 + wid) * 75 * Cs;
+  // merge the four waves' partial sums in wave order through LDS (sB is dead), then one coalesced slab per block
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wid == w) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row < 75) o[row * Cs + j * 32 + r] = acc[i][j][e];
-      }
+          for (int e = 0; e < 16; ++e) {
+            const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (row < 75) {
+              float* q = sB + row * Cs + j * 32 + r;
+              *q = (w == 0 ? 0.f : *q) + acc[i][j][e];
+            }
+          }
+    }
+  }
+  __syncthreads();
+  float* o = slab + (long long)blockIdx.x * 75 * Cs;
+  for (int i = threadIdx.x; i < 75 * Cs / 4; i += 256)
+    *reinterpret_cast<f32x4*>(o + i * 4) = *reinterpret_cast<const f32x4*>(sB + i * 4);
 }
 
-// dw[i] (+)= sum_k slab[k][i] : 64 outputs per block, 4 slab lanes per output, coalesced 256-B rows
+// dw[i] (+)= sum_k slab[k][i] : 16 outputs x 16 slab groups per block, merged in group order (deterministic)
 __global__ __launch_bounds__(256) void n3_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                              int nslab, int n, int accumulate) {
-  __shared__ float sr[4][64];
-  const int o = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  __shared__ float sr[16][17];
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int o = blockIdx.x * 16 + cl;
   float s = 0.f;
-  if (o < n)
-    for (int k = g; k < nslab; k += 4) s += slab[(long long)k * n + o];
-  sr[g][threadIdx.x & 63] = s;
+  if (o < n) {
+    int k = g;
+    for (; k + 48 < nslab; k += 64) {
+      const float a = slab[(long long)k * n + o], b = slab[(long long)(k + 16) * n + o];
+      const float c = slab[(long long)(k + 32) * n + o], d = slab[(long long)(k + 48) * n + o];
+      s += (a + b) + (c + d);
+    }
+    for (; k < nslab; k += 16) s += slab[(long long)k * n + o];
+  }
+  sr[g][cl] = s;
   __syncthreads();
   if (g == 0 && o < n) {
-    const int l = threadIdx.x & 63;
-    dw[o] = (accumulate ? dw[o] : 0.f) + ((sr[0][l] + sr[1][l]) + (sr[2][l] + sr[3][l]));
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sr[q][cl];
+    dw[o] = (accumulate ? dw[o] : 0.f) + t;
   }
 }
 
@@ -259,7 +281,7 @@ extern "C" int lg_n3_up_try(const float* src, const float* w, float* out, int B,
 
 extern "C" size_t lg_n3_wgrad_workspace_bytes(int B, int H, int W, int Cs) {
   const int ntiles = B * (H / 8) * (W / 16);
-  return (size_t)wgrad_blocks(ntiles > 0 ? ntiles : 1) * 4 * 75 * Cs * sizeof(float);
+  return (size_t)wgrad_blocks(ntiles > 0 ? ntiles : 1) * 75 * Cs * sizeof(float);
 }
 
 extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void* small16, float* dw, void* workspace,
@@ -287,7 +309,7 @@ extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void
   }
   LG_CHECK_LAUNCH("lg_n3_wgrad");
   const int n = 75 * Cs;
-  hipLaunchKernelGGL(n3_slab_reduce_kernel, dim3((n + 63) / 64), dim3(256), 0, st, (const float*)workspace, dw, nblk * 4, n,
+  hipLaunchKernelGGL(n3_slab_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, st, (const float*)workspace, dw, nblk, n,
                      accumulate);
   LG_CHECK_LAUNCH("lg_n3_wgrad(reduce)");
   return LG_OK;

@@ -256,6 +256,49 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
   }
 }
 
+// same for slabs with no row padding (rows_p == rows_v): 16-B accesses, 4 slabs in flight per thread
+__global__ __launch_bounds__(256) void slab_reduce4_kernel(const f32x4* __restrict__ slab, f32x4* __restrict__ out,
+                                                           int nsplit, long long n4, int accumulate) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 s = accumulate ? out[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {
+      const f32x4 a = slab[(long long)k * n4 + i], b = slab[(long long)(k + 1) * n4 + i];
+      const f32x4 c = slab[(long long)(k + 2) * n4 + i], d = slab[(long long)(k + 3) * n4 + i];
+      s += (a + b) + (c + d);
+    }
+    for (; k < nsplit; ++k) s += slab[(long long)k * n4 + i];
+    out[i] = s;
+  }
+}
+
+// db[c] (+)= sum_k partial[k][c]: 16 columns x 16 row groups per block, merged in group order (deterministic)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ db, int nb,
+                                                           int C, int accumulate) {
+  __shared__ float sr[16][17];
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s = 0.f;
+  if (c < C) {
+    int k = g;
+    for (; k + 48 < nb; k += 64) {
+      const float a = partial[(long long)k * C + c], b = partial[(long long)(k + 16) * C + c];
+      const float e = partial[(long long)(k + 32) * C + c], f = partial[(long long)(k + 48) * C + c];
+      s += (a + b) + (e + f);
+    }
+    for (; k < nb; k += 16) s += partial[(long long)k * C + c];
+  }
+  sr[g][cl] = s;
+  __syncthreads();
+  if (g == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sr[q][cl];
+    db[c] = (accumulate ? db[c] : 0.f) + t;
+  }
+}
+
 // column sums of a [M][C] matrix: partial[blk][C]
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, const __bf16* __restrict__ x16,
                                                      float* __restrict__ partial, long long M, int C, long long rows_per_blk) {
@@ -432,9 +475,16 @@ extern "C" int lg_conv_wgrad_m16(const float* big, const void* big16, const floa
   LG_CHECK_LAUNCH("lg_conv_wgrad");
   const int rows_v = patch ? 15 : cb;
   const long long n_out = (long long)p.ntaps * rows_v * cs;
-  const int rblocks = (int)((n_out + 255) / 256 < 2048 ? (n_out + 255) / 256 : 2048);
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(rblocks), dim3(256), 0, st, (const float*)workspace, dw, ns, p.ntaps,
-                     p.Cbp, rows_v, cs, accumulate);
+  if (rows_v == p.Cbp && n_out % 4 == 0 && (reinterpret_cast<size_t>(dw) & 15) == 0) {
+    const long long n4 = n_out / 4;
+    const int rb4 = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(slab_reduce4_kernel, dim3(rb4), dim3(256), 0, st, (const f32x4*)workspace, (f32x4*)dw, ns, n4,
+                       accumulate);
+  } else {
+    const int rblocks = (int)((n_out + 255) / 256 < 2048 ? (n_out + 255) / 256 : 2048);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rblocks), dim3(256), 0, st, (const float*)workspace, dw, ns, p.ntaps,
+                       p.Cbp, rows_v, cs, accumulate);
+  }
   LG_CHECK_LAUNCH("lg_conv_wgrad(reduce)");
   return LG_OK;
 }
@@ -465,9 +515,8 @@ extern "C" int lg_bias_grad_m16(const float* dy, const void* dy16, float* db, vo
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(colsum_kernel, dim3((int)nb), dim3(256), 0, st, dy, (const __bf16*)dy16, (float*)workspace, M, C, rpb);
   LG_CHECK_LAUNCH("lg_bias_grad");
-  const int rblocks = (C + 255) / 256;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(rblocks), dim3(256), 0, st, (const float*)workspace, db, (int)nb, 1, 1, 1,
-                     C, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)workspace, db, (int)nb, C,
+                     accumulate);
   LG_CHECK_LAUNCH("lg_bias_grad(reduce)");
   return LG_OK;
 }
