@@ -37,6 +37,8 @@ struct HaloParams {
   int nparts;
   int dry;                     // 1: only answer whether this kernel covers the shape (no launch)
   int res_budget;              // LDS bytes the resident-halo (RES) variant may use; 0 = variant off
+  int cfg;                     // tile-shape switches (LG_CFG env, A/B)
+  int* nparts_host;            // host-side: receives nparts of the launched tiling (moments epilogue on)
 };
 
 template <typename T> struct DT;
@@ -153,7 +155,10 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
 
   const int arow = tid / LPR, alc = tid % LPR;
   constexpr int NB = NT * KCH;  // B fragments (1 KiB each, 16 B per lane) of one tap for this wave's NT column tiles
-  u32x4 fb0[NB], fb1[NB], fb2[NB];  // three register sets: fragments are fetched two taps ahead of their use
+  // NSETS register sets of B fragments = the prefetch distance in taps; ~96 VGPRs of fragments in flight whatever the
+  // tap's size, so that the distance covers the L2 latency also for the short taps of KCH == 2 (8 MFMAs per tap)
+  constexpr int NSETS = (MT * NT == 4 && NB == 4) ? 6 : 3;  // deeper only where the tile is at 2 waves/SIMD anyway
+  u32x4 fb[NSETS][NB];
 
   int nit = nchunk * ntaps;  // flat (chunk, tap) iteration space
   const int KB = p.Cs * ESZ / 32, N32 = p.Npad >> 5;
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
     }
   };
 
-  // one tap: MFMAs out of `cur`, then refill `cur` with the fragments of tap it+3 (its MFMAs have been issued, in
+  // one tap: MFMAs out of `cur`, then refill `cur` with the fragments of tap it+NSETS (its MFMAs have been issued, in
   // order, so the registers are free).  Chunk boundary: every wave must be done with the old halo (barrier).
   int hsel = 0;
   auto iteration = [&](int it, u32x4 (&cur)[NB]) {
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
       }
     }
     if (!(p.dbg & 1)) compute(it, cur, hcur);
-    if (it + 3 < nit && !(p.dbg & 2)) load_frags(cur, it + 3);
+    if (it + NSETS < nit && !(p.dbg & 2)) load_frags(cur, it + NSETS);
     if (!RES && t + 1 == ntaps && it + 1 < nit && !(p.dbg & 4)) {
       __syncthreads();
       if constexpr (DBUF) {
@@ -337,17 +342,17 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    load_frags(fb0, 0);
-    if (nit > 1) load_frags(fb1, 1);
-    if (nit > 2) load_frags(fb2, 2);
+#pragma unroll
+    for (int u = 0; u < NSETS; ++u)
+      if (u < nit) load_frags(fb[u], u);
     if constexpr (!RES) {
       stage_halo(0, sH);
       __syncthreads();
     }
-    for (int it = 0; it < nit; it += 3) {
-      iteration(it, fb0);
-      if (it + 1 < nit) iteration(it + 1, fb1);
-      if (it + 2 < nit) iteration(it + 2, fb2);
+    for (int it = 0; it < nit; it += NSETS) {
+#pragma unroll
+      for (int u = 0; u < NSETS; ++u)
+        if (it + u < nit) iteration(it + u, fb[u]);
     }
 
     // ---- epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----------
@@ -439,6 +444,7 @@ int launch(HaloParams p, hipStream_t st) {
   }
   p.ntn = p.Npad / BN;
   p.nparts = (MODE == MODE_UP ? 4 : 1) * p.tpi * p.ntn;
+  if (p.nparts_host) *p.nparts_host = p.nparts;
   const int ntm = p.NI == 1 ? p.B * p.tpi : lg_cdiv(p.B, p.NI);
   dim3 grid(ntm * p.ntn, (MODE == MODE_UP && !RES) ? 4 : 1);
   auto kern = conv_halo_kernel<T, MODE, KCH, DBUF, SRC16, RES, WAVES_M, WAVES_N, MT, NT>;
@@ -454,6 +460,10 @@ int launch(HaloParams p, hipStream_t st) {
 
 template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES = false>
 int dispatch_bn2(const HaloParams& p, hipStream_t st) {
+  if constexpr (!DBUF && !RES) {  // tall wave tiles (128 rows x 64/32 cols): half the weight-fragment traffic per MFMA
+    if (p.Npad % 256 == 0 && (p.cfg & 1)) return launch<T, MODE, KCH, DBUF, SRC16, RES, 1, 4, 4, 2>(p, st);
+    if (p.Npad % 128 == 0 && (p.cfg & 2) && !(MODE == MODE_DOWN && p.NI > 1)) return launch<T, MODE, KCH, DBUF, SRC16, RES, 1, 4, 4, 1>(p, st);
+  }
   if (p.Npad % 128 == 0) return launch<T, MODE, KCH, DBUF, SRC16, RES, 2, 2, 2, 2>(p, st);
   if (p.Npad % 64 == 0) return launch<T, MODE, KCH, DBUF, SRC16, RES, 2, 2, 2, 1>(p, st);
   return launch<T, MODE, KCH, DBUF, SRC16, RES, 4, 1, 1, 1>(p, st);
@@ -527,12 +537,14 @@ extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const voi
     static int resb = -1;  // LG_RES_KB: LDS budget (KiB) of the resident-halo UP variant; 0 switches it off (A/B)
     if (resb < 0) { const char* e = getenv("LG_RES_KB"); resb = (e ? atoi(e) : 52) * 1024; }
     p.res_budget = resb;
+    static int cfg = -1;
+    if (cfg < 0) { const char* e = getenv("LG_CFG"); cfg = e ? atoi(e) : 2; }  // measured: bit 1 (128x32 wave tiles) on, bit 0 off
+    p.cfg = cfg;
   }
-  int nparts = 0;
+  int nparts = 0;  // set by launch<> to the partial records per sample of the tiling it chose
   if (spart && nparts_out && p.NI == 1 && act == 0) {
-    const int bn = p.Npad % 128 == 0 ? 128 : (p.Npad % 64 == 0 ? 64 : 32);  // same rule as dispatch_bn2
-    nparts = (mode == MODE_UP ? 4 : 1) * p.tpi * (p.Npad / bn);
-    if ((size_t)B * nparts * 3 * sizeof(double) <= spart_bytes) p.spart = (double*)spart; else nparts = 0;
+    const int worst = (mode == MODE_UP ? 4 : 1) * p.tpi * (p.Npad / 32);  // narrowest column tile
+    if ((size_t)B * worst * 3 * sizeof(double) <= spart_bytes) { p.spart = (double*)spart; p.nparts_host = &nparts; }
   }
   hipStream_t st = (hipStream_t)stream;
   int rc;

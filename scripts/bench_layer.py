@@ -12,6 +12,8 @@ LAYERS = [  # name, kind, Hs, cb, cs
     ("conv4 fwd 16->8", "down", 8, 256, 384), ("final s1t 128", "s1t", 128, 3, 32), ("conv1 dgrad 64->128", "up", 64, 3, 64),
     ("wgrad 16/32 (128,256)", "wgrad", 16, 128, 256), ("wgrad 64/128 (32,64)", "wgrad", 64, 32, 64),
 ]
+M16 = os.environ.get("LG_M16", "1") == "1" and dt == 1  # production bf16 path: sources read from their bf16 mirrors
+gm, bt = torch.ones(1, device="cuda"), torch.zeros(1, device="cuda")
 sel = sys.argv[1:] or None
 for name, kind, Hs, cb, cs in LAYERS:
     if sel and not any(s in name for s in sel):
@@ -24,9 +26,15 @@ for name, kind, Hs, cb, cs in LAYERS:
     if kind == "up":
         out = torch.empty(B, 2 * Hs, 2 * Hs, cb, device="cuda")
         fn = (lambda: ops.convT_s2_fwd(small, pack, bias_b, cb, dt, out=out)) if cb != 3 else (lambda: ops.conv2d_s2_dgrad(small, pack, cb, dt, out=out))
+        if M16 and cb != 3:
+            s16 = small.to(torch.bfloat16)
+            fn = lambda: ops.convT_s2_fwd_stats(small, pack, bias_b, cb, dt, gm, bt, x16=s16)
     elif kind == "down":
         out = torch.empty(B, Hs, Hs, cs, device="cuda")
         fn = lambda: ops.conv2d_s2_fwd(big, pack, bias_s, cs, dt, out=out)
+        if M16:
+            b16 = big.to(torch.bfloat16)
+            fn = lambda: ops.conv2d_s2_fwd_stats(big, pack, bias_s, cs, dt, gm, bt, x16=b16)
     elif kind == "s1t":
         out = torch.empty(B, Hs, Hs, cb, device="cuda")
         fn = lambda: ops.convT_s1_tanh_fwd(small, pack, bias_b, cb, dt, out=out)
