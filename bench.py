@@ -139,6 +139,14 @@ def main():
         # dominant kernel = the conv contraction class with the largest measured time
         tag, (n, fl, sec) = max(prof.items(), key=lambda kv: kv[1][2])
         ach = fl / sec / 1e12
+        # HBM-side bytes per launch of that kernel class: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) cannot run inside
+        # this process; they are collected on this same command and committed (scripts/pmc_traffic.py)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
+        if a.workload == "c3" and world == 1 and os.path.exists(tpath):
+            rec = json.load(open(tpath)).get(tag)
+            if rec:
+                traffic, traffic_src = rec["bytes_per_launch"], "profiles/r1_pmc_traffic.json (rocprofv3 --pmc, offline)"
         conv_sec = sum(v[2] for v in prof.values())
         conv_fl = sum(v[1] for v in prof.values())
         out = {
@@ -151,7 +159,8 @@ def main():
                        "global_batch": gb, "per_gpu_batch": args.batch_size, "image": 128, "cond_dim": 40,
                        "parallelism": f"dp{world}", "consumed_samples_per_step": 2 * gb},
             "roofline": {"bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": PEAK[dt_name], "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK[dt_name], 4), "traffic": None,
+                         "frac": round(ach / PEAK[dt_name], 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
                          "launches": n, "avg_launch_ms": round(sec / n * 1e3, 4),
                          "all_conv_kernels": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 2),
                                                   "ms_per_step": round(v[2] / a.steps * 1e3, 3)} for k, v in prof.items()},

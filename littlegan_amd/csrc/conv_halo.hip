@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
         for (int e = 0; e < 16; ++e) {
           const int row = (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
           const int o = so[row];
-          if (cok && o >= 0) {
+          if (cok && o >= 0 && !(p.dbg & 16)) {
             float v = acc[i][j][e] + bv;
             if (p.act == 1) v = tanhf(v);
             if (p.out16) p.out16[(long long)o * p.N + col] = (__bf16)v;
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
     // ---- fused InstanceNormalization moments of this block's output tile (one sample per block: NI == 1) ----------
     // {count, mean, M2 about the block mean}, merged per sample with Chan's formula by stats_final_kernel (norm.hip):
     // the separate pass that re-read the whole conv output for its moments is gone.
-    if (p.spart) {
+    if (p.spart && !(p.dbg & 32)) {
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
