@@ -73,8 +73,8 @@ def cpu_baseline(workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)    # >= 50 timed steps after 15 warm-up (partition steps included)
+    ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--workload", choices=["c3", "c2"], default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()

@@ -169,11 +169,13 @@ def test_golden_fixture_f32():
             assert d.mean() < 0.05 * cfg.lr * len(STEPS), (m, i, d.mean())
 
 
-@pytest.mark.parametrize("mfma", ["f32", "bf16"])
-def test_step_full_channels_one_step(mfma):
-    """Reference channel widths (384..32), 64x64 images, B=2: exercises every tile configuration."""
+@pytest.mark.parametrize("mfma,init_dim", [("f32", 4), ("bf16", 4), ("f32", 8), ("bf16", 8)])
+def test_step_full_channels_one_step(mfma, init_dim):
+    """Reference channel widths (384..32), B=2: 64x64 images (C1 shape) and 128x128 (the C2 / C3 benchmark shape, so
+    the exact layer geometries bench.py times are the ones checked here: resident-halo tiles, 128x32 wave tiles,
+    tap-product kernels of the 3-channel layers)."""
     tol = TOLS[mfma]
-    cfg = O.Cfg(init_dim=4, cond_dim=40, batch_size=2)
+    cfg = O.Cfg(init_dim=init_dim, cond_dim=40, batch_size=2)
     W = perturbed(cfg, 7)
     tr = build(cfg, W, mfma)
     inp = f32_round(O.make_inputs(cfg, 2, seed=9))
