@@ -54,6 +54,17 @@ class EagerTrainer:
         self.sync = GradSync(self.device)
         self.global_epoch = 1
         self._init_dir()
+        # eager_trainer.py:36-43: restore the newest checkpoint (weights, the three optimizers' slots and beta powers)
+        # and the epoch from status.json when args.restore is set
+        if getattr(args, "restore", False) and not getattr(args, "no_io", False) and getattr(args, "result_dir", None):
+            latest = self.latest_checkpoint()
+            if latest is not None:
+                print("Loading Checkpoint...")
+                self.load_checkpoint(latest)
+                st = os.path.join(args.result_dir, "checkpoint", "status.json")
+                if os.path.isfile(st):
+                    with open(st) as f:
+                        self.global_epoch = json.load(f)["epoch"]
         self._init_test_data()
 
     # ------------------------------------------------------------------ hot path
@@ -148,8 +159,22 @@ class EagerTrainer:
         return True, fake, adj, lg, ld, la
 
     # ------------------------------------------------------------------ eager_trainer.py:180-229
+    def _interrupted(self, signum, f_name):
+        """eager_trainer.py:171-178: SIGINT saves an "interrupt" checkpoint + status.json and exits 1."""
+        self.save_checkpoint("interrupt")
+        with open(os.path.join(self.args.result_dir, "checkpoint", "status.json"), "w") as f:
+            json.dump({"epoch": self.global_epoch}, f)
+        print("\n Checkpoint has been saved")
+        print(signum, f_name)
+        import sys
+        sys.exit(1)
+
     def train(self):
         a = self.args
+        io = not getattr(a, "no_io", False) and getattr(a, "result_dir", None)
+        if io:
+            import signal
+            signal.signal(signal.SIGINT, self._interrupted)
         for e in range(self.global_epoch, a.epoch + 1):
             print("Experiment:", a.exp_name, "Epoch:", e, "Starting...")
             self.global_epoch = e
@@ -177,6 +202,8 @@ class EagerTrainer:
                                  os.path.join(a.result_dir, "test", "adj", "%d-%d.jpg" % (e, b)))
             torch.cuda.synchronize()
             print("Time usage:", time.time() - start_time, "s")
+            if io:  # eager_trainer.py:229
+                self.save_checkpoint(str(e))
 
     # ------------------------------------------------------------------ eager_trainer.py:265-298
     def predict(self, noise, cond, image, gen_image_save_path=None, json_save_path=None, adj_image_save_path=None):
@@ -224,6 +251,53 @@ class EagerTrainer:
         it = self.dataset.get_new_iterator()
         self.test_image, self.test_cond = it.get_next()
         self.test_noise = torch.randn(self.test_cond.shape[0], self.args.noise_dim, device=self.device)
+
+    # ---- checkpoints (own format: the TF checkpoint format is out of scope, the CONTENT is the reference's:
+    # tf.train.Checkpoint(discriminator, generator, adjuster, three optimizers) eager_trainer.py:31-35)
+    def checkpoint_state(self) -> dict:
+        st = self.store
+        return {"format": "littlegan_amd-ckpt-1",
+                "names": {m: st.names(m) for m in "GDA"},
+                "flat": st.flat.detach().cpu(), "adam_m": st.m.detach().cpu(), "adam_v": st.v.detach().cpu(),
+                "beta_powers": {m: t.detach().cpu() for m, t in self.opt_state.items()},
+                "epoch": self.global_epoch}
+
+    def save_checkpoint(self, tag: str) -> str:
+        d = os.path.join(self.args.result_dir, "checkpoint")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, f"ckpt-{tag}.pt")
+        tmp = path + ".tmp"
+        torch.save(self.checkpoint_state(), tmp)
+        os.replace(tmp, path)  # a killed save never leaves a truncated "latest"
+        with open(os.path.join(d, "checkpoint"), "w") as f:  # same role as TF's "checkpoint" index file
+            json.dump({"latest": os.path.basename(path)}, f)
+        return path
+
+    def latest_checkpoint(self) -> Optional[str]:
+        d = os.path.join(self.args.result_dir, "checkpoint")
+        idx = os.path.join(d, "checkpoint")
+        if not os.path.isfile(idx):
+            return None
+        with open(idx) as f:
+            p = os.path.join(d, json.load(f)["latest"])
+        return p if os.path.isfile(p) else None
+
+    def load_checkpoint(self, path: str):
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        st = self.store
+        if ck.get("format") != "littlegan_amd-ckpt-1":
+            raise ValueError(f"{path}: not a littlegan_amd checkpoint")
+        for m in "GDA":
+            if ck["names"][m] != st.names(m):
+                raise ValueError(f"{path}: weight list of {m} does not match this model configuration")
+        if ck["flat"].numel() != st.flat.numel():
+            raise ValueError(f"{path}: {ck['flat'].numel()} parameters, this configuration has {st.flat.numel()}")
+        st.flat.copy_(ck["flat"])
+        st.m.copy_(ck["adam_m"])
+        st.v.copy_(ck["adam_v"])
+        for m, t in ck["beta_powers"].items():
+            self.opt_state[m].copy_(t)
+        st.bump()
 
     def export_model_checkpoint(self):
         path = os.path.join(self.args.result_dir, "model", "model.pt")

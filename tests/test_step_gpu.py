@@ -186,3 +186,48 @@ def test_step_full_channels_one_step(mfma, init_dim):
     for got, key in ((lg, "gen_loss"), (ld, "disc_loss"), (la, "adj_loss")):
         assert abs(got.item() - ref[key]) < tol["loss"] * abs(ref[key])
     check_grads(tr, ref, (("D", "dD"), ("G", "dG"), ("A", "dA")), tol)
+
+
+def test_checkpoint_resume_is_bit_exact(tmp_path):
+    """Own-format checkpoint with the reference's CONTENT (eager_trainer.py:31-43: the three models, the three
+    optimizers' slots and beta powers, status.json epoch): train 3 steps, save, train a 4th; a fresh trainer that
+    restores the checkpoint and runs the same 4th step must land on the same bits."""
+    from littlegan_amd.eager_trainer import EagerTrainer
+    from littlegan_amd.model import Adjuster, Decoder, Discriminator, Encoder, Generator
+    cfg = O.Cfg(init_dim=2, conv_filter=(32, 32, 32, 32, 32), cond_dim=3, noise_dim=5, batch_size=2)
+
+    def mk(restore):
+        args = make_args(cfg, "f32")
+        args.no_io, args.result_dir, args.restore, args.exp_name, args.epoch = False, str(tmp_path), restore, "t", 1
+        dec, enc = Decoder(args), Encoder(args)
+        g = Generator(args, dec)
+        d = Discriminator(args, enc)
+        return EagerTrainer(args, g, d, Adjuster(args, d, g), None)
+
+    tr = mk(False)
+    load_weights(tr, perturbed(cfg, 3))
+    inps = [dev_inputs(f32_round(O.make_inputs(cfg, cfg.batch_size, seed=70 + b))) for b in range(4)]
+    for b in range(3):
+        tr.train_step_from_inputs(9 + b, inps[b])   # 9, 10 (a partition step), 11 (Adjuster branch on)
+    tr.global_epoch = 7
+    path = tr.save_checkpoint("7")
+    with open(os.path.join(str(tmp_path), "checkpoint", "status.json"), "w") as f:
+        import json
+        json.dump({"epoch": 7}, f)
+    assert tr.latest_checkpoint() == path
+    tr.train_step_from_inputs(12, inps[3])
+    want = tr.store.flat.clone()
+
+    tr2 = mk(True)  # restores in the constructor
+    assert tr2.global_epoch == 7
+    tr2.train_step_from_inputs(12, inps[3])
+    assert torch.equal(tr2.store.flat, want)
+    # a checkpoint of another configuration is refused, loudly
+    cfg2 = O.Cfg(init_dim=2, conv_filter=(32, 32, 32, 32, 32), cond_dim=4, noise_dim=5, batch_size=2)
+    a2 = make_args(cfg2, "f32")
+    dec, enc = Decoder(a2), Encoder(a2)
+    g = Generator(a2, dec)
+    d = Discriminator(a2, enc)
+    tr3 = EagerTrainer(a2, g, d, Adjuster(a2, d, g), None)
+    with pytest.raises(ValueError):
+        tr3.load_checkpoint(path)
