@@ -33,6 +33,10 @@ extern "C" int lg_n3_p16_supported(int H, int W, int C);
 extern "C" int lg_n3_s1t_fwd_p16_try(const void* x16, const float* w, const float* bias, float* y, int B, int H, int W,
                                      int C, void* stream);
 extern "C" int lg_n3_up_p16_try(const void* src16, const float* w, float* out, int B, int H, int W, int C, void* stream);
+extern "C" int lg_n3_conv1_fwd_p16_try(const float* img, const float* w, const float* bias, float* z, int B, int H, int W,
+                                       int N, void* spart, size_t spart_bytes, int* nparts, void* stream);
+extern "C" int lg_n3_s1_dgrad_p16_try(const float* dpre, const float* w, float* dx, void* dx16, int B, int H, int W, int N,
+                                      void* stream);
 static bool n3_enabled() {
   static int v = -1;
   if (v < 0) v = getenv("LG_NO_N3") ? 0 : 1;  // A/B switch
@@ -78,7 +82,14 @@ extern "C" int lg_conv2d_s2_fwd_stats(const float* x, const void* x16, const voi
                                       int Hs, int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes,
                                       int* nparts, void* stream) {
   if (nparts) *nparts = 0;
-  if (cb == 3) return run_down(x, pack, bias, y, B, Hs, Ws, cb, cs, dtype, stream);
+  if (cb == 3) {
+    if (dtype == LG_DT_BF16 && n3_enabled()) {  // bf16 path: patch kernel with coalesced row stores + fused moments
+      const int rc = lg_n3_conv1_fwd_p16_try(x, raw_pack(pack, cb, cs, dtype), bias, y, B, Hs, Ws, cs, spart, spart_bytes,
+                                             nparts, stream);
+      if (rc != LG_ERR_UNSUPPORTED) return rc;
+    }
+    return run_down(x, pack, bias, y, B, Hs, Ws, cb, cs, dtype, stream);
+  }
   return lg_conv_igemm_ex(MODE_DOWN, dtype, x, x16, pack, bias, y, nullptr, B, Hs, Ws, cb, cs, 0, 0, 0, spart, spart_bytes,
                           nparts, stream);
 }
@@ -230,7 +241,10 @@ extern "C" int lg_convT_s1_tanh_bwd_m16(const float* x, const void* x16, const f
   LG_CHECK_ARG(!(dx && dx16), "lg_convT_s1_tanh_bwd: give dx or dx16, not both");
   int rc;
   if (dx || dx16) {  // dx[i,ci] = sum_k,co dpre[i+k-2,co] W[k,co,ci]  -> patch conv, stride 1, pad 2
-    rc = lg_conv_igemm_ex(MODE_PATCH, dtype, dpre, nullptr, pack, nullptr, dx, dx16, B, H, W, 3, cs, 0, 1, 2, nullptr, 0,
+    rc = LG_ERR_UNSUPPORTED;
+    if (dtype == LG_DT_BF16 && n3_enabled())
+      rc = lg_n3_s1_dgrad_p16_try(dpre, raw_pack(pack, cb, cs, dtype), dx, dx16, B, H, W, cs, stream);
+    if (rc == LG_ERR_UNSUPPORTED) rc = lg_conv_igemm_ex(MODE_PATCH, dtype, dpre, nullptr, pack, nullptr, dx, dx16, B, H, W, 3, cs, 0, 1, 2, nullptr, 0,
                           nullptr, stream);
     if (rc) return rc;
   }

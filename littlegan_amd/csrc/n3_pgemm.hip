@@ -156,6 +156,154 @@ __global__ __launch_bounds__(256) void up_p16_kernel(const __bf16* __restrict__ 
   }
 }
 
+
+// --------------------------------------------------------------------------------------------------------------
+// "patch" layers: the 3-channel tensor is the SOURCE (K = 5*5*3 = 75, N = 32 or 64 wide).
+//   S = 2, pad 1 : Encoder.conv1 forward        z[B,H,W,N]   = conv2d_s2(img[B,2H,2W,3]) + b        model.py:15
+//   S = 1, pad 2 : final layer's data gradient  dx[B,H,W,N]  = sum_{k,co} dpre[i+k-2][co] W[k][co][:]  model.py:86-87
+// Both are  out[o][n] = b[n] + sum_k patch(o)[k] * w[k*N + n],  k = (ky, kx, c3).  For a fixed ky the 15 values
+// (kx, c3) are 15 CONSECUTIVE floats of source row S*y+ky-pad starting at pixel S*x-pad, so K is laid out as 6 groups
+// of 16 (15 real + 1 zero-weight slot; group 5 all zero-weight): a 16x16x32 A fragment is 8 consecutive floats of an
+// LDS image tile per lane, no index table.  These layers are bound by their OUTPUT stream (N floats per pixel), so
+// the C tiles go through LDS and leave as 16-B-per-lane stores of whole contiguous rows; the conv1 form also emits
+// the per-block InstanceNorm moments {count, mean, M2} (same record as conv_halo.hip) so no pass re-reads z.
+// --------------------------------------------------------------------------------------------------------------
+template <int S, int N, bool OUT16, bool STATS>
+__global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict__ src, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        __bf16* __restrict__ out16, double* __restrict__ spart, int B,
+                                                        int H, int W, int pad) {
+  constexpr int NT = N / 16, HSIDE = S * (TS - 1) + 5, ROWF = HSIDE * 3, TROWS = HSIDE + 2;
+  constexpr int MTW = TS / 4;  // m-tiles (tile rows of 16 pixels) per wave
+  __shared__ __attribute__((aligned(16))) float tile[TROWS * ROWF + 4];
+  __shared__ __attribute__((aligned(16))) float cst[4][16 * N];
+  __shared__ double sred[20];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int tpx = W / TS, tpi = tpx * (H / TS), ntiles = B * tpi;
+  const int Hs = S * H, Ws = S * W;
+
+  // B fragments (constant for the block): lane (n = l&15, g) holds k' = 32 ks + 8 g + j, group ky = k'/16, slot kk = k'%16
+  bf16x8 bf[3][NT];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int kp = 32 * ks + 8 * g + j, ky = kp >> 4, kk = kp & 15;
+        v[j] = (ky < 5 && kk < 15) ? (__bf16)w[(long long)(ky * 15 + kk) * N + nt * 16 + r] : (__bf16)0.f;
+      }
+      bf[ks][nt] = v;
+    }
+  float bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bv[nt] = bias ? bias[nt * 16 + r] : 0.f;
+  for (int i = HSIDE * ROWF + threadIdx.x; i < TROWS * ROWF + 4; i += 256) tile[i] = 0.f;  // rows the zero-weight slots touch
+
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int n = t / tpi, tt = t - n * tpi;
+    const int y0 = (tt / tpx) * TS, x0 = (tt % tpx) * TS;
+    __syncthreads();  // previous tile fully consumed
+    for (int i = threadIdx.x; i < HSIDE * HSIDE; i += 256) {
+      const int hy = i / HSIDE, hx = i - hy * HSIDE;
+      const int sy = S * y0 - pad + hy, sx = S * x0 - pad + hx;
+      float a = 0.f, b = 0.f, c = 0.f;
+      if ((unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws) {
+        const float* q = src + ((long long)(n * Hs + sy) * Ws + sx) * 3;
+        a = q[0]; b = q[1]; c = q[2];
+      }
+      float* d = tile + (hy * HSIDE + hx) * 3;
+      d[0] = a; d[1] = b; d[2] = c;
+    }
+    __syncthreads();
+
+    f32x4 acc[MTW][NT];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      const int ly = wid * MTW + i;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[i][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const int ky = 2 * ks + (g >> 1), kk = 8 * (g & 1);
+        const float* ap = tile + (S * ly + ky) * ROWF + S * r * 3 + kk;
+        bf16x8 a;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = (__bf16)ap[j];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[ks][nt], acc[i][nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][nt][e] += bv[nt];
+    }
+
+    if constexpr (STATS) {  // moments of this block's 256 x N outputs (one sample per block)
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sm += acc[i][nt][e];
+      const double cnt = 256.0 * N;
+      double red[1] = {(double)sm};
+      lg_block_sum_d<1>(red, sred);
+      if (threadIdx.x == 0) sred[16] = red[0] / cnt;
+      __syncthreads();
+      const float mean = (float)sred[16];
+      float m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = acc[i][nt][e] - mean; m2 += d * d; }
+      const double meand = sred[16];
+      double red2[1] = {(double)m2};
+      lg_block_sum_d<1>(red2, sred);
+      if (threadIdx.x == 0) {
+        double* o = spart + ((long long)n * tpi + tt) * 3;
+        const double df = (double)mean - meand;
+        o[0] = cnt; o[1] = meand; o[2] = red2[0] - cnt * df * df;
+      }
+    }
+
+    // C tiles -> LDS (C layout: col = lane&15, row = 4(lane>>4)+e) -> whole contiguous pixel rows, 16 B per lane
+    float* cw = cst[wid];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      const int ly = wid * MTW + i;
+      __syncthreads();
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cw[(4 * g + e) * N + nt * 16 + r] = acc[i][nt][e];
+      __syncthreads();
+      const long long o0 = ((long long)(n * H + y0 + ly) * W + x0) * N;  // 16 pixels x N contiguous
+      if constexpr (OUT16) {
+#pragma unroll
+        for (int q = 0; q < 16 * N / 8 / 64; ++q) {
+          const int idx = q * 64 + lane;
+          const f32x4 a = *reinterpret_cast<const f32x4*>(cw + idx * 8), b = *reinterpret_cast<const f32x4*>(cw + idx * 8 + 4);
+          bf16x8 v;
+          v[0] = (__bf16)a[0]; v[1] = (__bf16)a[1]; v[2] = (__bf16)a[2]; v[3] = (__bf16)a[3];
+          v[4] = (__bf16)b[0]; v[5] = (__bf16)b[1]; v[6] = (__bf16)b[2]; v[7] = (__bf16)b[3];
+          *reinterpret_cast<bf16x8*>(out16 + o0 + idx * 8) = v;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16 * N / 4 / 64; ++q) {
+          const int idx = q * 64 + lane;
+          *reinterpret_cast<f32x4*>(out + o0 + idx * 4) = *reinterpret_cast<const f32x4*>(cw + idx * 4);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // ---- entry points (LG_ERR_UNSUPPORTED -> the caller falls back to the fp32-source kernels) ----
@@ -179,5 +327,34 @@ extern "C" int lg_n3_up_p16_try(const void* src16, const float* w, float* out, i
   if (C == 32) hipLaunchKernelGGL(up_p16_kernel<32>, grid, dim3(256), 0, st, (const __bf16*)src16, w, out, B, H, W);
   else hipLaunchKernelGGL(up_p16_kernel<64>, grid, dim3(256), 0, st, (const __bf16*)src16, w, out, B, H, W);
   LG_CHECK_LAUNCH("lg_n3_up_p16");
+  return LG_OK;
+}
+
+// conv1 forward from the fp32 image (bf16 MFMA), with the per-block InstanceNorm moments; *nparts = records per sample
+extern "C" int lg_n3_conv1_fwd_p16_try(const float* img, const float* w, const float* bias, float* z, int B, int H, int W,
+                                       int N, void* spart, size_t spart_bytes, int* nparts, void* stream) {
+  if (nparts) *nparts = 0;
+  if (H % TS || W % TS || N != 64 || !img || !w || !z) return LG_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int tpi = (H / TS) * (W / TS), ntiles = B * tpi;
+  const dim3 grid(ntiles < 4096 ? ntiles : 4096);
+  const bool stats = spart && nparts && (size_t)B * tpi * 3 * sizeof(double) <= spart_bytes;
+  if (stats) hipLaunchKernelGGL((patch_p16_kernel<2, 64, false, true>), grid, dim3(256), 0, st, img, w, bias, z, nullptr, (double*)spart, B, H, W, 1);
+  else hipLaunchKernelGGL((patch_p16_kernel<2, 64, false, false>), grid, dim3(256), 0, st, img, w, bias, z, nullptr, nullptr, B, H, W, 1);
+  LG_CHECK_LAUNCH("lg_n3_conv1_fwd_p16");
+  if (stats) *nparts = tpi;
+  return LG_OK;
+}
+
+// data gradient of the final stride-1 layer: dpre [B,H,W,3] fp32 -> dx [B,H,W,32] as bf16 (dx16) or fp32 (dx)
+extern "C" int lg_n3_s1_dgrad_p16_try(const float* dpre, const float* w, float* dx, void* dx16, int B, int H, int W, int N,
+                                      void* stream) {
+  if (H % TS || W % TS || N != 32 || !dpre || !w || (!dx && !dx16)) return LG_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int ntiles = B * (H / TS) * (W / TS);
+  const dim3 grid(ntiles < 4096 ? ntiles : 4096);
+  if (dx16) hipLaunchKernelGGL((patch_p16_kernel<1, 32, true, false>), grid, dim3(256), 0, st, dpre, w, nullptr, nullptr, (__bf16*)dx16, nullptr, B, H, W, 2);
+  else hipLaunchKernelGGL((patch_p16_kernel<1, 32, false, false>), grid, dim3(256), 0, st, dpre, w, nullptr, dx, nullptr, nullptr, B, H, W, 2);
+  LG_CHECK_LAUNCH("lg_n3_s1_dgrad_p16");
   return LG_OK;
 }

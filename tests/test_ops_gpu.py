@@ -373,3 +373,35 @@ def test_norm_apply_mirror_only(ops):
     y = ops.instnorm_apply(x, st, None, 0, 1, 0.3, out16=y16a)
     assert ops.instnorm_apply(x, st, None, 0, 1, 0.3, out16=y16b, want_f32=False) is None
     assert torch.equal(y16a, y16b) and torch.equal(y16a, y.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16), (1, 32, 48), (3, 16, 32)])
+def test_n3_patch_kernels_bf16(ops, case):
+    """bf16 path of the layers whose SOURCE is the 3-channel tensor (patch_p16_kernel): Encoder.conv1 forward with the
+    fused InstanceNorm moments, and the data gradient of the final stride-1 layer (fp32 and bf16 output).  Against
+    the oracle on the same bf16-rounded operands the error is fp32 accumulation only."""
+    B, H, W = case
+    rng = np.random.default_rng(zlib_crc(case))
+    # conv1: img [B,2H,2W,3] -> z [B,H,W,64]
+    img = r32(rng, B, 2 * H, 2 * W, 3)
+    w1 = r32(rng, 5, 5, 3, 64, scale=0.1)
+    b1 = r32(rng, 64, scale=0.1)
+    pack1 = ops.conv_pack(dev(w1), 3, 64, 1)
+    gm, bt = dev(np.array([1.1])), dev(np.array([0.05]))
+    z, st = ops.conv2d_s2_fwd_stats(dev(img), pack1, dev(b1), 64, 1, gm, bt)
+    z_e = O.conv2d(_bf16_round(img), _bf16_round(w1), b1, 2)
+    assert rel(z, z_e) < 3e-5
+    assert st is not None, "the patch kernel must deliver the moments (no separate statistics pass)"
+    zf = z.double().reshape(B, -1)
+    assert rel(st[:, 0], zf.mean(1).cpu().numpy()) < 1e-6 and rel(st[:, 1], zf.std(1, unbiased=False).cpu().numpy()) < 1e-6
+    # final layer data gradient: dpre [B,H,W,3] -> dx [B,H,W,32]
+    w = r32(rng, 5, 5, 3, 32, scale=0.05)
+    dpre = r32(rng, B, H, W, 3)
+    pack = ops.conv_pack(dev(w), 3, 32, 1)
+    dx_e = O.conv2d_transpose_bwd(np.zeros((B, H, W, 32)), _bf16_round(w), _bf16_round(dpre), 1)[0]
+    dx = torch.empty(B, H, W, 32, device="cuda")
+    ops.convT_s1_tanh_bwd(None, dev(dpre), pack, 32, 1, dx=dx)
+    assert rel(dx, dx_e) < 3e-5
+    dx16 = torch.empty(B, H, W, 32, dtype=torch.bfloat16, device="cuda")
+    ops.convT_s1_tanh_bwd(None, dev(dpre), pack, 32, 1, dx16=dx16)
+    assert torch.equal(dx16, dx.to(torch.bfloat16))
