@@ -121,8 +121,9 @@ class Encoder(_ConvStack):
         """keep_maps=False: the caller only uses the LAST map; in the bf16 path the fp32 copies of maps 1-3 are then
         not written where the next conv reads the bf16 mirror (their list entries are None).
         tails (optional): the 4 maps this encoder already produced for MORE samples that follow `inputs` in the
-        batch (same weights); they are appended to the outputs instead of being recomputed (the Adjuster's input is
-        [img1 ; fake] and D has just encoded `fake`).  Every op is per-sample, so the result is identical."""
+        batch (same weights); each returned map is then the pair (own map, tail) instead of a recomputation or a
+        concatenated copy (the Adjuster's input is [img1 ; fake] and D has just encoded `fake`).  Every op is
+        per-sample, so the result is identical."""
         x = inputs
         a = self.args.leaky_alpha
         packs = self.packs()
@@ -142,11 +143,9 @@ class Encoder(_ConvStack):
                     0, self.dtype, z.shape[0], z.shape[1] // 2, z.shape[2] // 2, cs, self.chans[i][1]))
                 h = ops.instnorm_apply(z, st, None, 0, 1, a, out16=h16, want_f32=not drop32)
                 outs.append(h)
-            else:
-                full = torch.empty((B1 + tails[i - 1].shape[0],) + tuple(z.shape[1:]), dtype=torch.float32, device=z.device)
-                h = ops.instnorm_apply(z, st, None, 0, 1, a, out=full[:B1], out16=h16)
-                full[B1:].copy_(tails[i - 1])
-                outs.append(full)
+            else:  # the map of the whole batch is the PAIR (own part, tail): no concatenated copy is made
+                h = ops.instnorm_apply(z, st, None, 0, 1, a, out16=h16)
+                outs.append((h, tails[i - 1]))
             saved.append((x, z, st, x16))
             x, x16 = h, h16
         if ctx is not None:
@@ -209,8 +208,8 @@ class Decoder(_ConvStack):
         a = self.args.leaky_alpha
         packs = self.packs()
         saved = []
-        if add[0] is not None:
-            x = x + add[0]  # tiny (init_dim^2 x conv_filter[0]); later skips are fused into the norm-apply pass
+        if add[0] is not None:  # tiny (init_dim^2 x conv_filter[0]); later skips are fused into the norm-apply pass
+            x = x + (torch.cat(add[0], 0) if isinstance(add[0], tuple) else add[0])
         m16 = self.dtype == DT_BF16
         x16 = None
         for i, (cb, cs) in enumerate(self.chans, 1):
@@ -229,7 +228,14 @@ class Decoder(_ConvStack):
                 drop32 = want16 = m16 and ops.n3_m16_supported(z.shape[1], z.shape[2], self.args.image_channel, cb,
                                                                self.dtype)
             h16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if want16 else None
-            h = ops.instnorm_apply(z, st, skip, 0, 1, a, out16=h16, want_f32=not drop32)
+            if isinstance(skip, tuple):  # skip given as (first rows, remaining rows) of the batch: one apply per part
+                b1 = skip[0].shape[0]
+                h = None if drop32 else torch.empty_like(z)
+                for lo, hi, sk in ((0, b1, skip[0]), (b1, z.shape[0], skip[1])):
+                    ops.instnorm_apply(z[lo:hi], st[lo:hi], sk, 0, 1, a, out=None if drop32 else h[lo:hi],
+                                       out16=h16[lo:hi] if h16 is not None else None, want_f32=not drop32)
+            else:
+                h = ops.instnorm_apply(z, st, skip, 0, 1, a, out16=h16, want_f32=not drop32)
             saved.append((x, z, st, x16))
             x, x16 = h, h16
         if ctx is not None:
