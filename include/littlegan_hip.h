@@ -129,6 +129,12 @@ int lg_instnorm_leaky_apply(const float* x, const float* stats, const float* ski
 int lg_instnorm_leaky_bwd(const float* x, const float* stats, const void* g, int g_is_bf16, float* dx, void* dx16,
                           float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, int B, long long L,
                           int pre_leaky, int post_leaky, float alpha, int accumulate, void* stream);
+/* same, plus db[C] (+)= column sums of dx viewed as [B*L/C][C]: the bias gradient of the conv layer that produced x
+ * (C = its channels, innermost), taken in the pass that writes dx (no separate lg_bias_grad pass over dx) */
+size_t lg_instnorm_bwd_db_workspace_bytes(int B, long long L, int C);
+int lg_instnorm_leaky_bwd_db(const float* x, const float* stats, const void* g, int g_is_bf16, float* dx, void* dx16,
+                             float* dgamma, float* dbeta, float* db, int C, void* workspace, size_t ws_bytes, int B,
+                             long long L, int pre_leaky, int post_leaky, float alpha, int accumulate, void* stream);
 
 /* ---- tf.compat.v1.layers.Dense  model.py:62-63 (heads, sigmoid), :83, :120 ----------------------- */
 int lg_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, void* stream);

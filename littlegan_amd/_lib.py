@@ -50,6 +50,8 @@ SIGNATURES = {
     "lg_instnorm_stats_finalize": (I, [P, I, P, P, P, I, P]),
     "lg_instnorm_leaky_apply": (I, [P, P, P, P, P, I, L, I, I, F, P]),
     "lg_instnorm_leaky_bwd": (I, [P, P, P, I, P, P, P, P, P, Z, I, L, I, I, F, I, P]),
+    "lg_instnorm_bwd_db_workspace_bytes": (Z, [I, L, I]),
+    "lg_instnorm_leaky_bwd_db": (I, [P, P, P, I, P, P, P, P, P, I, P, Z, I, L, I, I, F, I, P]),
     "lg_dense_fwd": (I, [P, P, P, P, I, I, I, P]),
     "lg_dense_wgrad": (I, [P, P, P, P, I, I, I, I, P]),
     "lg_heads_fwd_workspace_bytes": (Z, [I, I, I]),

@@ -206,11 +206,18 @@ __global__ __launch_bounds__(256) void bwd_affine_grad_kernel(const double* __re
   }
 }
 
+// DB: also the column sums of dx over (sample, position) = the bias gradient of the conv that produced x ([.., C]
+// channels innermost).  The launch makes gridDim.x*256 a multiple of C/4, so a thread meets the same 4 channels in
+// every trip; threads of a block are merged in thread order into colpart[block][C] (deterministic), blocks by
+// colsum_final (below).
+template <bool DB>
 __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict__ x, const void* __restrict__ g, int g16,
                                                         const float* __restrict__ stats, const float* __restrict__ bstats,
                                                         float* __restrict__ dx, __bf16* __restrict__ dx16, long long L4,
-                                                        long long total4, int pre_leaky, int post_leaky, float alpha) {
+                                                        long long total4, int pre_leaky, int post_leaky, float alpha,
+                                                        float* __restrict__ colpart, int C4) {
   const long long stride = (long long)gridDim.x * blockDim.x;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
     const int n = (int)(i / L4);
     const float* sp = stats + (long long)n * LG_NSTAT;
@@ -236,6 +243,45 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
       w[0] = (__bf16)o[0]; w[1] = (__bf16)o[1]; w[2] = (__bf16)o[2]; w[3] = (__bf16)o[3];
       *reinterpret_cast<bf16x4*>(dx16 + i * 4) = w;
     }
+    if constexpr (DB) csum += o;
+  }
+  if constexpr (DB) {
+    __shared__ f32x4 sacc[256];
+    sacc[threadIdx.x] = csum;
+    __syncthreads();
+    const int q = threadIdx.x;  // channel quad
+    if (q < C4) {
+      const int base = (int)(((long long)blockIdx.x * 256) % C4);
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      for (int k = (q - base + C4) % C4; k < 256; k += C4) t += sacc[k];
+      *reinterpret_cast<f32x4*>(colpart + ((long long)blockIdx.x * C4 + q) * 4) = t;
+    }
+  }
+}
+
+// db[c] (+)= sum_k part[k][c]: 16 columns x 16 row groups per block, merged in group order (deterministic)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ db, int nb,
+                                                           int C, int accumulate) {
+  __shared__ float sr[16][17];
+  const int cl = threadIdx.x & 15, gq = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s = 0.f;
+  if (c < C) {
+    int k = gq;
+    for (; k + 48 < nb; k += 64) {
+      const float a = partial[(long long)k * C + c], b = partial[(long long)(k + 16) * C + c];
+      const float e = partial[(long long)(k + 32) * C + c], f = partial[(long long)(k + 48) * C + c];
+      s += (a + b) + (e + f);
+    }
+    for (; k < nb; k += 16) s += partial[(long long)k * C + c];
+  }
+  sr[gq][cl] = s;
+  __syncthreads();
+  if (gq == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sr[q][cl];
+    db[c] = (accumulate ? db[c] : 0.f) + t;
   }
 }
 
@@ -296,12 +342,36 @@ extern "C" int lg_instnorm_leaky_apply(const float* x, const float* stats, const
 
 // g = dL/d(apply output before skip); writes dx = dL/dx, (accumulates) dgamma, dbeta
 // g: dL/dy as fp32, or as bf16 when g_is_bf16; dx and dx16: fp32 result and/or its bf16 mirror (at least one)
+constexpr int DB_MAX_BLOCKS = 2046;  // multiple of 3: gridDim*256 must be a multiple of C/4 (C/4 = 96 for 384 channels)
+
+extern "C" size_t lg_instnorm_bwd_db_workspace_bytes(int B, long long L, int C) {
+  return lg_instnorm_workspace_bytes(B, L) + (size_t)DB_MAX_BLOCKS * (size_t)C * sizeof(float);
+}
+
+extern "C" int lg_instnorm_leaky_bwd_db(const float* x, const float* stats, const void* g, int g_is_bf16, float* dx, void* dx16,
+                                        float* dgamma, float* dbeta, float* db, int C, void* workspace, size_t ws_bytes, int B,
+                                        long long L, int pre_leaky, int post_leaky, float alpha, int accumulate, void* stream);
+
 extern "C" int lg_instnorm_leaky_bwd(const float* x, const float* stats, const void* g, int g_is_bf16, float* dx, void* dx16,
                                      float* dgamma, float* dbeta, void* workspace, size_t ws_bytes, int B, long long L, int pre_leaky,
                                      int post_leaky, float alpha, int accumulate, void* stream) {
+  return lg_instnorm_leaky_bwd_db(x, stats, g, g_is_bf16, dx, dx16, dgamma, dbeta, nullptr, 0, workspace, ws_bytes, B, L,
+                                  pre_leaky, post_leaky, alpha, accumulate, stream);
+}
+
+// as lg_instnorm_leaky_bwd; db (may be null): db[C] (+)= column sums of dx viewed as [B*L/C][C] — the bias gradient of the
+// conv layer whose output x is (C = its channel count, innermost), taken in the same pass that writes dx
+extern "C" int lg_instnorm_leaky_bwd_db(const float* x, const float* stats, const void* g, int g_is_bf16, float* dx, void* dx16,
+                                        float* dgamma, float* dbeta, float* db, int C, void* workspace, size_t ws_bytes, int B,
+                                        long long L, int pre_leaky, int post_leaky, float alpha, int accumulate, void* stream) {
   LG_CHECK_ARG(x && stats && g && (dx || dx16) && workspace, "lg_instnorm_leaky_bwd: null pointer");
   LG_CHECK_ARG(B > 0 && B <= 65535 && L > 0 && L % 4 == 0, "lg_instnorm_leaky_bwd: bad shape B=%d L=%lld", B, L);
   LG_CHECK_ARG(ws_bytes >= lg_instnorm_workspace_bytes(B, L), "lg_instnorm_leaky_bwd: workspace too small");
+  if (db) {
+    LG_CHECK_ARG(C > 0 && C % 4 == 0 && C / 4 <= 256 && L % C == 0 && (256 % (C / 4) == 0 || 768 % (C / 4) == 0),
+                 "lg_instnorm_leaky_bwd_db: unsupported channel count C=%d (L=%lld)", C, L);
+    LG_CHECK_ARG(ws_bytes >= lg_instnorm_bwd_db_workspace_bytes(B, L, C), "lg_instnorm_leaky_bwd_db: workspace too small");
+  }
   hipStream_t st = (hipStream_t)stream;
   const int nc = nchunks(L);
   char* ws = (char*)workspace;
@@ -319,8 +389,22 @@ extern "C" int lg_instnorm_leaky_bwd(const float* x, const float* stats, const v
     LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd(affine)");
   }
   const long long total4 = (long long)B * L / 4;
-  hipLaunchKernelGGL(bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(256), 0, st, x, g, g_is_bf16, stats, (const float*)bstats, dx,
-                     (__bf16*)dx16, L / 4, total4, pre_leaky, post_leaky, alpha);
-  LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd(apply)");
+  if (!db) {
+    hipLaunchKernelGGL(bwd_apply_kernel<false>, dim3(ew_blocks(total4)), dim3(256), 0, st, x, g, g_is_bf16, stats,
+                       (const float*)bstats, dx, (__bf16*)dx16, L / 4, total4, pre_leaky, post_leaky, alpha, nullptr, 0);
+    LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd(apply)");
+    return LG_OK;
+  }
+  const int C4 = C / 4, unit = 256 % C4 == 0 ? 1 : 3;  // blocks per period of the thread -> channel map
+  long long nb = (total4 + 255) / 256;
+  if (nb > DB_MAX_BLOCKS) nb = DB_MAX_BLOCKS;
+  nb = (nb + unit - 1) / unit * unit;
+  float* colpart = (float*)(ws + lg_instnorm_workspace_bytes(B, L));
+  hipLaunchKernelGGL(bwd_apply_kernel<true>, dim3((int)nb), dim3(256), 0, st, x, g, g_is_bf16, stats, (const float*)bstats, dx,
+                     (__bf16*)dx16, L / 4, total4, pre_leaky, post_leaky, alpha, colpart, C4);
+  LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd_db(apply)");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)colpart, db, (int)nb, C,
+                     accumulate);
+  LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd_db(bias)");
   return LG_OK;
 }

@@ -179,10 +179,10 @@ class Encoder(_ConvStack):
             else:
                 drop32 = m16 and ops.n3_m16_supported(z.shape[1], z.shape[2], cb, cs, self.dtype)
                 dz16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if drop32 else None
-            dz = ops.instnorm_bwd(z, st, g_h, dgm, dbt, 0, 1, a, out16=dz16, want_f32=not drop32)
+            dz = ops.instnorm_bwd(z, st, g_h, dgm, dbt, 0, 1, a, out16=dz16, want_f32=not drop32,
+                                  db=self._g[f"conv{i}.bias"] if need_wgrad else None)  # bias gradient = column sums of dz
             if need_wgrad:
                 ops.conv2d_s2_wgrad(x, dz, self._g[f"conv{i}.kernel"], False, self.dtype, x16=x16, dy16=dz16)
-                ops.bias_grad(dz, self._g[f"conv{i}.bias"], dy16=dz16 if drop32 else None)
             # the gradient handed to the next (lower) level's norm backward stays bf16 in the bf16 path; the image
             # gradient of level 1 is fp32 (consumed by the loss / tanh backward)
             g_h = (ops.conv2d_s2_dgrad(dz, packs[i - 1], cb, self.dtype, dy16=dz16, out_bf16=(self.dtype == DT_BF16 and i > 1))
@@ -255,10 +255,10 @@ class Decoder(_ConvStack):
             dz16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if self.dtype == DT_BF16 else None
             drop32 = (dz16 is not None and (not need_wgrad or x16 is not None) and
                       ops.conv_halo_supported(0, self.dtype, z.shape[0], z.shape[1] // 2, z.shape[2] // 2, cb, cs))
-            dz = ops.instnorm_bwd(z, st, g_h, dgm, dbt, 0, 1, a, out16=dz16, want_f32=not drop32)
+            dz = ops.instnorm_bwd(z, st, g_h, dgm, dbt, 0, 1, a, out16=dz16, want_f32=not drop32,
+                                  db=self._g[f"conv{i}.bias"] if need_wgrad else None)
             if need_wgrad:
                 ops.convT_s2_wgrad(x, dz, self._g[f"conv{i}.kernel"], False, self.dtype, x16=x16, dy16=dz16)
-                ops.bias_grad(dz, self._g[f"conv{i}.bias"], dy16=dz16 if drop32 else None)
             g_h = ops.convT_s2_dgrad(dz, packs[i - 1], cs, self.dtype, dy16=dz16, out_bf16=(self.dtype == DT_BF16 and i > 1))
         return g_h
 

@@ -337,9 +337,10 @@ def instnorm_apply(x, stats, skip, pre_leaky, post_leaky, alpha, out=None, out16
 
 
 def instnorm_bwd(x, stats, g, dgamma, dbeta, pre_leaky, post_leaky, alpha, accumulate=False, out=None, out16=None,
-                 want_f32=True):
+                 want_f32=True, db=None):
     """g may be fp32 or bf16 (as written by a bf16 data-gradient conv).  Returns the fp32 dx (or None if want_f32 is
-    False, in which case only the bf16 mirror out16 is written)."""
+    False, in which case only the bf16 mirror out16 is written).  db [C] (optional, C = x.shape[-1]): receives the
+    column sums of dx = the bias gradient of the conv layer that produced x, in the same pass."""
     B = x.shape[0]
     Ln = x.numel() // B
     _chk(x, name="x")
@@ -362,10 +363,14 @@ def instnorm_bwd(x, stats, g, dgamma, dbeta, pre_leaky, post_leaky, alpha, accum
     if out16 is not None:
         _chk16(out16, x, "out16")
     lib = _lib.load()
-    ws = workspace(int(lib.lg_instnorm_workspace_bytes(B, Ln)), x.device, "small")
-    check(lib.lg_instnorm_leaky_bwd(_p(x), _p(stats), _p(g), int(g16), _p(out), _p(out16), _p(dgamma), _p(dbeta), _p(ws),
-                                    ws.numel(), B, Ln, int(pre_leaky), int(post_leaky), float(alpha), int(accumulate),
-                                    _stream()), "lg_instnorm_leaky_bwd")
+    C = 0
+    if db is not None:
+        C = x.shape[-1]
+        _chk(db, (C,), "db")
+    ws = workspace(int(lib.lg_instnorm_bwd_db_workspace_bytes(B, Ln, C)), x.device, "small")
+    check(lib.lg_instnorm_leaky_bwd_db(_p(x), _p(stats), _p(g), int(g16), _p(out), _p(out16), _p(dgamma), _p(dbeta), _p(db),
+                                       C, _p(ws), ws.numel(), B, Ln, int(pre_leaky), int(post_leaky), float(alpha),
+                                       int(accumulate), _stream()), "lg_instnorm_leaky_bwd_db")
     return out
 
 

@@ -405,3 +405,28 @@ def test_n3_patch_kernels_bf16(ops, case):
     dx16 = torch.empty(B, H, W, 32, dtype=torch.bfloat16, device="cuda")
     ops.convT_s1_tanh_bwd(None, dev(dpre), pack, 32, 1, dx16=dx16)
     assert torch.equal(dx16, dx.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("shape", [(3, 4, 4, 32), (2, 8, 8, 384), (5, 16, 16, 64), (2, 6, 10, 128)])
+@pytest.mark.parametrize("g16", [False, True])
+def test_instnorm_bwd_fused_bias_column_sums(ops, shape, g16):
+    """db of lg_instnorm_leaky_bwd_db = column sums of the dx it writes (the conv bias gradient), same pass."""
+    rng = np.random.default_rng(zlib_crc(shape))
+    x, g = dev(r32(rng, *shape) * 1.3 + 0.2), dev(r32(rng, *shape))
+    if g16:
+        g = g.to(torch.bfloat16)
+    gm, bt = dev(np.array([1.2])), dev(np.array([0.1]))
+    st = ops.instnorm_stats(x, gm, bt, 0, 0.3)
+    C = shape[-1]
+    db = torch.full((C,), 7.0, device="cuda")
+    d16 = torch.empty(x.shape, dtype=torch.bfloat16, device="cuda")
+    dx = ops.instnorm_bwd(x, st, g, None, None, 0, 1, 0.3, out16=d16, db=db)
+    dx_plain = ops.instnorm_bwd(x, st, g, None, None, 0, 1, 0.3)
+    assert torch.equal(dx, dx_plain) and torch.equal(d16, dx.to(torch.bfloat16))
+    exp = dx.double().reshape(-1, C).sum(0).cpu().numpy()
+    scale = np.abs(dx.double().cpu().numpy()).reshape(-1, C).sum(0).max()   # the sums cancel to ~0: compare to the mass
+    assert np.abs(db.cpu().numpy() - exp).max() < 2e-6 * scale
+    # mirror-only output (no fp32 dx) gives the same sums
+    db2 = torch.empty(C, device="cuda")
+    ops.instnorm_bwd(x, st, g, None, None, 0, 1, 0.3, out16=d16, want_f32=False, db=db2)
+    assert torch.equal(db, db2)
