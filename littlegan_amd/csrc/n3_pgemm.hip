@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict_
   constexpr int MTW = TS / 4;  // m-tiles (tile rows of 16 pixels) per wave
   __shared__ __attribute__((aligned(16))) float tile[TROWS * ROWF + 4];
   __shared__ __attribute__((aligned(16))) float cst[4][16 * N];
-  __shared__ double sred[20];
+  __shared__ double sred[40];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const int tpx = W / TS, tpi = tpx * (H / TS), ntiles = B * tpi;
   const int Hs = S * H, Ws = S * W;
@@ -218,12 +218,17 @@ __global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict_
     }
     __syncthreads();
 
-    f32x4 acc[MTW][NT];
-#pragma unroll
+    // one m-tile (a tile row of 16 pixels) at a time: MFMAs -> + bias -> moments -> wave-private LDS transpose -> whole
+    // contiguous rows out, 16 B per lane.  No block barrier in here: LDS operations of one wave execute in order.
+    float s1 = 0.f, s2 = 0.f;  // sum and sum of squares about `shift` (the first bias: close enough to the block mean)
+    const float shift = STATS ? (bias ? bias[0] : 0.f) : 0.f;
+    float* cw = cst[wid];
+#pragma unroll 1
     for (int i = 0; i < MTW; ++i) {
       const int ly = wid * MTW + i;
+      f32x4 acc[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[i][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 3; ++ks) {
         const int ky = 2 * ks + (g >> 1), kk = 8 * (g & 1);
@@ -232,56 +237,17 @@ __global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = (__bf16)ap[j];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[ks][nt], acc[i][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[ks][nt], acc[nt], 0, 0, 0);
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][nt][e] += bv[nt];
-    }
-
-    if constexpr (STATS) {  // moments of this block's 256 x N outputs (one sample per block)
-      float sm = 0.f;
-#pragma unroll
-      for (int i = 0; i < MTW; ++i)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sm += acc[i][nt][e];
-      const double cnt = 256.0 * N;
-      double red[1] = {(double)sm};
-      lg_block_sum_d<1>(red, sred);
-      if (threadIdx.x == 0) sred[16] = red[0] / cnt;
-      __syncthreads();
-      const float mean = (float)sred[16];
-      float m2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < MTW; ++i)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { const float d = acc[i][nt][e] - mean; m2 += d * d; }
-      const double meand = sred[16];
-      double red2[1] = {(double)m2};
-      lg_block_sum_d<1>(red2, sred);
-      if (threadIdx.x == 0) {
-        double* o = spart + ((long long)n * tpi + tt) * 3;
-        const double df = (double)mean - meand;
-        o[0] = cnt; o[1] = meand; o[2] = red2[0] - cnt * df * df;
-      }
-    }
-
-    // C tiles -> LDS (C layout: col = lane&15, row = 4(lane>>4)+e) -> whole contiguous pixel rows, 16 B per lane
-    float* cw = cst[wid];
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-      const int ly = wid * MTW + i;
-      __syncthreads();
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cw[(4 * g + e) * N + nt * 16 + r] = acc[i][nt][e];
-      __syncthreads();
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc[nt][e] + bv[nt];
+          if constexpr (STATS) { const float d = v - shift; s1 += d; s2 += d * d; }
+          cw[(4 * g + e) * N + nt * 16 + r] = v;  // C layout: col = lane&15, row = 4(lane>>4)+e
+        }
+      __builtin_amdgcn_wave_barrier();
       const long long o0 = ((long long)(n * H + y0 + ly) * W + x0) * N;  // 16 pixels x N contiguous
       if constexpr (OUT16) {
 #pragma unroll
@@ -299,6 +265,18 @@ __global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict_
           const int idx = q * 64 + lane;
           *reinterpret_cast<f32x4*>(out + o0 + idx * 4) = *reinterpret_cast<const f32x4*>(cw + idx * 4);
         }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    if constexpr (STATS) {  // moments of this block's 256 x N outputs (one sample per block): {count, mean, M2}
+      const double cnt = 256.0 * N;
+      double red[2] = {(double)s1, (double)s2};
+      lg_block_sum_d<2>(red, sred);
+      if (threadIdx.x == 0) {
+        double* o = spart + ((long long)n * tpi + tt) * 3;
+        const double md = red[0] / cnt;  // mean - shift
+        o[0] = cnt; o[1] = (double)shift + md; o[2] = red[1] - cnt * md * md;
       }
     }
   }
