@@ -151,35 +151,44 @@ __global__ __launch_bounds__(256) void bwd_partial_kernel(const float* __restric
                                                           const float* __restrict__ stats, double* __restrict__ partial,
                                                           long long L, int nchunk, int pre_leaky, int post_leaky,
                                                           float alpha) {
-  const int n = blockIdx.y, ch = blockIdx.x;
-  const long long base = (long long)n * L + (long long)ch * CHUNK;
-  const long long lim = L - (long long)ch * CHUNK;
+  // gridDim.x blocks per sample, each sweeping chunks blockIdx.x, blockIdx.x + gridDim.x, ... (few long-lived blocks
+  // stream better than one short block per chunk), ONE block reduction at the end; nchunk = gridDim.x partial records
+  const int n = blockIdx.y;
   const float* sp = stats + (long long)n * LG_NSTAT;
   const float mu = sp[0], a = sp[2], b = sp[3], mul = sp[4];
-  const double mud = (double)mu + (double)mul;
   __shared__ double sred[32];
   double s1 = 0.0, s2 = 0.0;
+  for (long long c0 = (long long)blockIdx.x * CHUNK; c0 < L; c0 += (long long)gridDim.x * CHUNK) {
+   const long long base = (long long)n * L + c0;
+   const long long lim = L - c0;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+   for (int q = 0; q < 4; ++q) {
     const int e = (q * 256 + threadIdx.x) * 4;
     if (e < lim) {
       const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + e);
       const f32x4 gv = load_g4(g, base + e, g16);
+      // the 4 values of a quad are summed in fp32 (c = (x - mu_hi) - mu_lo is the float-float centred value the
+      // forward pass uses, so no coherent error enters), the quads in fp64: the fp64 VALU rate, not HBM, bounded this pass
+      float q1 = 0.f, q2 = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float xx = xv[k];
         if (pre_leaky) xx = lg_leaky(xx, alpha);
+        const float c = (xx - mu) - mul;
         float dz = gv[k];
-        if (post_leaky) dz = (a * ((xx - mu) - mul) + b > 0.f) ? dz : alpha * dz;
-        s1 += (double)dz;
-        s2 += (double)dz * ((double)xx - mud);
+        if (post_leaky) dz = (a * c + b > 0.f) ? dz : alpha * dz;
+        q1 += dz;
+        q2 += dz * c;
       }
+      s1 += (double)q1;
+      s2 += (double)q2;
     }
+   }
   }
   double red[2] = {s1, s2};
   lg_block_sum_d<2>(red, sred);
   if (threadIdx.x == 0) {
-    double* o = partial + ((long long)n * nchunk + ch) * 2;
+    double* o = partial + ((long long)n * nchunk + blockIdx.x) * 2;
     o[0] = red[0]; o[1] = red[1];
   }
 }
@@ -403,7 +412,9 @@ extern "C" int lg_instnorm_leaky_bwd_db(const float* x, const float* stats, cons
     LG_CHECK_ARG(ws_bytes >= lg_instnorm_bwd_db_workspace_bytes(B, L, C), "lg_instnorm_leaky_bwd_db: workspace too small");
   }
   hipStream_t st = (hipStream_t)stream;
-  const int nc = nchunks(L);
+  int nc = 4096 / B;  // bwd_partial blocks per sample: ~4096 long-lived blocks in all (the buffer is sized for nchunks(L))
+  if (nc < 1) nc = 1;
+  if (nc > nchunks(L)) nc = nchunks(L);
   char* ws = (char*)workspace;
   double* partial = (double*)ws;
   float* bstats = (float*)(ws + part_bytes(B, L));
