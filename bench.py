@@ -170,7 +170,7 @@ def main():
             "losses_last_step": losses,
             "parity": "checked against the in-repo fp64 restatement (tests/); parity to TensorFlow 1.15 is UNPINNED",
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0), on a bounded sample
             out["cpu_baseline"] = cpu_baseline(a.workload)
         print(json.dumps(out), flush=True)
     if world > 1:
