@@ -17,6 +17,16 @@
 namespace {
 
 enum { MODE_DOWN = 0, MODE_UP = 1, MODE_S1T = 2 };
+// DOWN from the bf16 mirror with 32-channel chunks keeps its halo rows UNPADDED (64 B) and XOR-swizzled instead of
+// padded to 80 B: 665 rows x 64 B = 42.5 KB, so THREE blocks fit a CU's 160 KB (the padded image allowed two), and the
+// 128x32 wave tile of that variant is compiled for 3 waves per SIMD (161 VGPRs, no spills).  The A fragments of
+// 8 consecutive lanes sit in rows R, R+2, .. (stride-2 conv): rows R and R+4 share their banks, so the 16-B slot is
+// XORed with (row >> 2) & 3 -> conflict-free ds_read_b128.
+// (selected per launch as the W3 template flag: worth it when the grid fills 3 slots per CU in fewer rounds)
+template <typename T, int MODE, int KCH, bool SRC16, bool RES, int WAVES_M, int MT, int NT>
+constexpr bool halo_w3_ok() {
+  return MODE == MODE_DOWN && KCH == 2 && SRC16 && !RES && sizeof(T) == 2 && WAVES_M == 1 && MT == 4 && NT == 1;
+}
 
 struct HaloParams {
   const float* src;
@@ -67,15 +77,17 @@ __device__ __forceinline__ void tap_info(int mode, int cls, int t, int& dy, int&
 // RES ("resident"): UP mode from the bf16 mirror with the halo of ALL Cs channels staged once; the block then runs the
 // four parity classes one after the other out of that image (grid.y == 1): a quarter of the source traffic and no
 // barrier at all inside the (class, chunk, tap) loops.
-template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES, int WAVES_M, int WAVES_N, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
+template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES, int WAVES_M, int WAVES_N, int MT, int NT, bool W3 = false>
+__global__ __launch_bounds__(256, (W3 ? 3 : 2)) void conv_halo_kernel(const HaloParams p) {
+  static_assert(!W3 || halo_w3_ok<T, MODE, KCH, SRC16, RES, WAVES_M, MT, NT>(), "W3: DOWN, 32-channel chunks, bf16 mirror, 128x32 wave tile");
   static_assert(!SRC16 || (sizeof(T) == 2 && !DBUF), "bf16 source only with bf16 MFMA, single-buffered halo");
   static_assert(!RES || (SRC16 && MODE == MODE_UP), "resident halo: UP mode from the bf16 mirror");
   constexpr int ESZ = DT<T>::ESZ;
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
   static_assert(BM == 128, "halo tiles are 128 rows");
   constexpr int KC = KCH * 32 / ESZ;
-  const int ROWB = RES ? p.Cs * ESZ + 16 : KCH * 32 + 16;    // LDS bytes per halo row (RES: all channels)
+  constexpr bool SWZ = W3;
+  const int ROWB = RES ? p.Cs * ESZ + 16 : (SWZ ? KCH * 32 : KCH * 32 + 16);    // LDS bytes per halo row (RES: all channels)
   const int LPR = RES ? p.Cs / 8 : (SRC16 ? KC / 8 : KC / 4);  // threads per halo row (16 B each: 4 fp32 or 8 bf16 channels)
   const int RPP = 256 / LPR;         // halo rows per pass
   constexpr int SS = (MODE == MODE_DOWN) ? 2 : 1;
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
           const int hr = hr0 + u * RPP + arow;
-          if (hr < p.nrows) *reinterpret_cast<u32x4*>(sH + hr * ROWB + alc * 16) = v[u];
+          if (hr < p.nrows) *reinterpret_cast<u32x4*>(sH + hr * ROWB + ((SWZ ? (alc ^ ((hr >> 2) & 3)) : alc) << 4)) = v[u];
         }
       } else {
         f32x4 v[SU];
@@ -247,7 +259,11 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
       } else {
         bf16x8 a[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sH + (hb[i] + toff) * ROWB + h * 16 + q * 32);
+        for (int i = 0; i < MT; ++i) {
+          const int row = hb[i] + toff;
+          if constexpr (SWZ) a[i] = *reinterpret_cast<const bf16x8*>(sH + row * ROWB + (((2 * q + h) ^ ((row >> 2) & 3)) << 4));
+          else a[i] = *reinterpret_cast<const bf16x8*>(sH + row * ROWB + h * 16 + q * 32);
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -431,10 +447,10 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const HaloParams p) {
 
 constexpr int LDS_BUDGET = 80 * 1024;  // two blocks per CU (160 KiB)
 
-template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES, int WAVES_M, int WAVES_N, int MT, int NT>
+template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES, int WAVES_M, int WAVES_N, int MT, int NT, bool W3 = false>
 int launch(HaloParams p, hipStream_t st) {
   constexpr int BN = WAVES_N * NT * 32;
-  const int ROWB = RES ? p.Cs * DT<T>::ESZ + 16 : KCH * 32 + 16;
+  const int ROWB = RES ? p.Cs * DT<T>::ESZ + 16 : (W3 ? KCH * 32 : KCH * 32 + 16);
   const size_t lds = (((RES ? 4 : 1) * 128 + p.nrows) * 4 + 15) / 16 * 16 + (size_t)p.nrows * ROWB * (DBUF ? 2 : 1);
   if (lds > (size_t)(RES ? p.res_budget : LDS_BUDGET)) return LG_ERR_UNSUPPORTED;
   if (DBUF) {  // the interleaved prefetch must fit its register window: ceil(NU/(ntaps-1)) <= 4 with the fewest taps
@@ -447,7 +463,7 @@ int launch(HaloParams p, hipStream_t st) {
   if (p.nparts_host) *p.nparts_host = p.nparts;
   const int ntm = p.NI == 1 ? p.B * p.tpi : lg_cdiv(p.B, p.NI);
   dim3 grid(ntm * p.ntn, (MODE == MODE_UP && !RES) ? 4 : 1);
-  auto kern = conv_halo_kernel<T, MODE, KCH, DBUF, SRC16, RES, WAVES_M, WAVES_N, MT, NT>;
+  auto kern = conv_halo_kernel<T, MODE, KCH, DBUF, SRC16, RES, WAVES_M, WAVES_N, MT, NT, W3>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RES ? 160 * 1024 : LDS_BUDGET);
@@ -462,7 +478,13 @@ template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES = false
 int dispatch_bn2(const HaloParams& p, hipStream_t st) {
   if constexpr (!DBUF && !RES) {  // tall wave tiles (128 rows x 64/32 cols): half the weight-fragment traffic per MFMA
     if (p.Npad % 256 == 0 && (p.cfg & 1)) return launch<T, MODE, KCH, DBUF, SRC16, RES, 1, 4, 4, 2>(p, st);
-    if (p.Npad % 128 == 0 && (p.cfg & 2) && !(MODE == MODE_DOWN && p.NI > 1)) return launch<T, MODE, KCH, DBUF, SRC16, RES, 1, 4, 4, 1>(p, st);
+    if (p.Npad % 128 == 0 && (p.cfg & 2) && !(MODE == MODE_DOWN && p.NI > 1)) {
+      if constexpr (halo_w3_ok<T, MODE, KCH, SRC16, RES, 1, 4, 1>()) {
+        // three resident blocks per CU: measured better on the whole step than a rounds-of-the-grid heuristic (LG_CFG bit 2 = off)
+        if (!(p.cfg & 4)) return launch<T, MODE, KCH, DBUF, SRC16, RES, 1, 4, 4, 1, true>(p, st);
+      }
+      return launch<T, MODE, KCH, DBUF, SRC16, RES, 1, 4, 4, 1>(p, st);
+    }
   }
   if (p.Npad % 128 == 0) return launch<T, MODE, KCH, DBUF, SRC16, RES, 2, 2, 2, 2>(p, st);
   if (p.Npad % 64 == 0) return launch<T, MODE, KCH, DBUF, SRC16, RES, 2, 2, 2, 1>(p, st);
