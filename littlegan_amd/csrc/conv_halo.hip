@@ -25,7 +25,9 @@ enum { MODE_DOWN = 0, MODE_UP = 1, MODE_S1T = 2 };
 // (selected per launch as the W3 template flag: worth it when the grid fills 3 slots per CU in fewer rounds)
 template <typename T, int MODE, int KCH, bool SRC16, bool RES, int WAVES_M, int MT, int NT>
 constexpr bool halo_w3_ok() {
-  return MODE == MODE_DOWN && KCH == 2 && SRC16 && !RES && sizeof(T) == 2 && WAVES_M == 1 && MT == 4 && NT == 1;
+  return SRC16 && !RES && sizeof(T) == 2 &&
+         ((MODE == MODE_DOWN && KCH == 2 && ((WAVES_M == 1 && MT == 4 && NT == 1) || (WAVES_M == 2 && MT == 2 && NT == 1))) ||
+          (MODE == MODE_UP && KCH == 4 && WAVES_M == 1 && MT == 4 && NT == 1));  // the tiles that fit 168 VGPRs (nearly) unspilled
 }
 
 struct HaloParams {
@@ -79,14 +81,14 @@ __device__ __forceinline__ void tap_info(int mode, int cls, int t, int& dy, int&
 // barrier at all inside the (class, chunk, tap) loops.
 template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES, int WAVES_M, int WAVES_N, int MT, int NT, bool W3 = false>
 __global__ __launch_bounds__(256, (W3 ? 3 : 2)) void conv_halo_kernel(const HaloParams p) {
-  static_assert(!W3 || halo_w3_ok<T, MODE, KCH, SRC16, RES, WAVES_M, MT, NT>(), "W3: DOWN, 32-channel chunks, bf16 mirror, 128x32 wave tile");
+  static_assert(!W3 || halo_w3_ok<T, MODE, KCH, SRC16, RES, WAVES_M, MT, NT>(), "W3: DOWN, 32-channel chunks, bf16 mirror, 128x32 / 64x32 wave tiles");
   static_assert(!SRC16 || (sizeof(T) == 2 && !DBUF), "bf16 source only with bf16 MFMA, single-buffered halo");
   static_assert(!RES || (SRC16 && MODE == MODE_UP), "resident halo: UP mode from the bf16 mirror");
   constexpr int ESZ = DT<T>::ESZ;
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
   static_assert(BM == 128, "halo tiles are 128 rows");
   constexpr int KC = KCH * 32 / ESZ;
-  constexpr bool SWZ = W3;
+  constexpr bool SWZ = W3 && MODE == MODE_DOWN;
   const int ROWB = RES ? p.Cs * ESZ + 16 : (SWZ ? KCH * 32 : KCH * 32 + 16);    // LDS bytes per halo row (RES: all channels)
   const int LPR = RES ? p.Cs / 8 : (SRC16 ? KC / 8 : KC / 4);  // threads per halo row (16 B each: 4 fp32 or 8 bf16 channels)
   const int RPP = 256 / LPR;         // halo rows per pass
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256, (W3 ? 3 : 2)) void conv_halo_kernel(const Halo
   constexpr int NB = NT * KCH;  // B fragments (1 KiB each, 16 B per lane) of one tap for this wave's NT column tiles
   // NSETS register sets of B fragments = the prefetch distance in taps; ~96 VGPRs of fragments in flight whatever the
   // tap's size, so that the distance covers the L2 latency also for the short taps of KCH == 2 (8 MFMAs per tap)
-  constexpr int NSETS = (MT * NT == 4 && NB == 4) ? 6 : 3;  // deeper only where the tile is at 2 waves/SIMD anyway
+  constexpr int NSETS = (W3 && MODE == MODE_UP) ? 2 : ((MT * NT == 4 && NB == 4) ? 6 : 3);  // deeper only where registers allow
   u32x4 fb[NSETS][NB];
 
   int nit = nchunk * ntaps;  // flat (chunk, tap) iteration space
@@ -450,7 +452,7 @@ constexpr int LDS_BUDGET = 80 * 1024;  // two blocks per CU (160 KiB)
 template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES, int WAVES_M, int WAVES_N, int MT, int NT, bool W3 = false>
 int launch(HaloParams p, hipStream_t st) {
   constexpr int BN = WAVES_N * NT * 32;
-  const int ROWB = RES ? p.Cs * DT<T>::ESZ + 16 : (W3 ? KCH * 32 : KCH * 32 + 16);
+  const int ROWB = RES ? p.Cs * DT<T>::ESZ + 16 : ((W3 && MODE == MODE_DOWN) ? KCH * 32 : KCH * 32 + 16);
   const size_t lds = (((RES ? 4 : 1) * 128 + p.nrows) * 4 + 15) / 16 * 16 + (size_t)p.nrows * ROWB * (DBUF ? 2 : 1);
   if (lds > (size_t)(RES ? p.res_budget : LDS_BUDGET)) return LG_ERR_UNSUPPORTED;
   if (DBUF) {  // the interleaved prefetch must fit its register window: ceil(NU/(ntaps-1)) <= 4 with the fewest taps
@@ -478,16 +480,21 @@ template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES = false
 int dispatch_bn2(const HaloParams& p, hipStream_t st) {
   if constexpr (!DBUF && !RES) {  // tall wave tiles (128 rows x 64/32 cols): half the weight-fragment traffic per MFMA
     if (p.Npad % 256 == 0 && (p.cfg & 1)) return launch<T, MODE, KCH, DBUF, SRC16, RES, 1, 4, 4, 2>(p, st);
-    if (p.Npad % 128 == 0 && (p.cfg & 2) && !(MODE == MODE_DOWN && p.NI > 1)) {
+    if (p.Npad % 128 == 0 && (p.cfg & 2) && (!(MODE == MODE_DOWN && p.NI > 1) || (halo_w3_ok<T, MODE, KCH, SRC16, RES, 1, 4, 1>() && (p.cfg & 8)))) {
       if constexpr (halo_w3_ok<T, MODE, KCH, SRC16, RES, 1, 4, 1>()) {
         // three resident blocks per CU: measured better on the whole step than a rounds-of-the-grid heuristic (LG_CFG bit 2 = off)
-        if (!(p.cfg & 4)) return launch<T, MODE, KCH, DBUF, SRC16, RES, 1, 4, 4, 1, true>(p, st);
+        if (!(p.cfg & 4) && (MODE == MODE_DOWN || (p.cfg & 32))) return launch<T, MODE, KCH, DBUF, SRC16, RES, 1, 4, 4, 1, true>(p, st);
       }
       return launch<T, MODE, KCH, DBUF, SRC16, RES, 1, 4, 4, 1>(p, st);
     }
   }
   if (p.Npad % 128 == 0) return launch<T, MODE, KCH, DBUF, SRC16, RES, 2, 2, 2, 2>(p, st);
-  if (p.Npad % 64 == 0) return launch<T, MODE, KCH, DBUF, SRC16, RES, 2, 2, 2, 1>(p, st);
+  if (p.Npad % 64 == 0) {
+    if constexpr (!DBUF && halo_w3_ok<T, MODE, KCH, SRC16, RES, 2, 2, 1>()) {
+      if (!(p.cfg & 16)) return launch<T, MODE, KCH, DBUF, SRC16, RES, 2, 2, 2, 1, true>(p, st);
+    }
+    return launch<T, MODE, KCH, DBUF, SRC16, RES, 2, 2, 2, 1>(p, st);
+  }
   return launch<T, MODE, KCH, DBUF, SRC16, RES, 4, 1, 1, 1>(p, st);
 }
 template <typename T, int MODE, int KCH>
@@ -560,7 +567,7 @@ extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const voi
     if (resb < 0) { const char* e = getenv("LG_RES_KB"); resb = (e ? atoi(e) : 52) * 1024; }
     p.res_budget = resb;
     static int cfg = -1;
-    if (cfg < 0) { const char* e = getenv("LG_CFG"); cfg = e ? atoi(e) : 2; }  // measured: bit 1 (128x32 wave tiles) on, bit 0 off
+    if (cfg < 0) { const char* e = getenv("LG_CFG"); cfg = e ? atoi(e) : 42; }  // measured: bits 1 (128x32 wave tiles), 3 (also for small maps with W3), 5 (W3 for UP) on
     p.cfg = cfg;
   }
   int nparts = 0;  // set by launch<> to the partial records per sample of the tiling it chose
