@@ -358,13 +358,29 @@ inline TileSel pick_tile(int cbp, int cs) {
   return s;
 }
 
-inline int pick_nsplit(int tiles, int M, int KP) {
-  int ns = (1024 + tiles - 1) / tiles;
-  const int maxs = M / (4 * KP) > 0 ? M / (4 * KP) : 1;
-  if (ns > maxs) ns = maxs;
-  if (ns < 1) ns = 1;
-  if (ns > 256) ns = 256;
-  return ns;
+// resident block slots of the whole chip for a tile shape (LDS-limited: 2 buffers of KP x (BI + BJ) operand rows)
+inline int wgrad_slots(int bi, int bj, bool bf16_kernel) {
+  const int KP = bf16_kernel ? 64 : 32, ESZ = bf16_kernel ? 2 : 4, padb = bf16_kernel ? 16 : 0;
+  const size_t lds = 2 * (size_t)KP * ((bi * ESZ + padb) + (bj * ESZ + padb));
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 8) per_cu = 8;
+  if (per_cu < 1) per_cu = 1;
+  return 256 * per_cu;
+}
+
+// split-K factor: the grid runs in rounds of `slots` blocks, each block costs its K range plus a fixed part (prologue,
+// slab write) -> minimise rounds x (M/ns + K0); a 2.05-round grid wastes a third of the machine
+inline int pick_nsplit(int tiles, int M, int KP, int slots) {
+  const int maxs = M / (4 * KP) > 0 ? (M / (4 * KP) < 256 ? M / (4 * KP) : 256) : 1;
+  const long long K0 = 1536;
+  int best = 1;
+  long long best_cost = -1;
+  for (int ns = 1; ns <= maxs; ++ns) {
+    const long long rounds = ((long long)tiles * ns + slots - 1) / slots;
+    const long long cost = rounds * ((M + ns - 1) / ns + K0) + 24LL * ns;  // + the ordered reduce over ns slabs
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ns; }
+  }
+  return best;
 }
 
 }  // namespace
@@ -385,7 +401,7 @@ static size_t wgrad_ws_generic(int B, int Hm, int Wm, int cb, int cs, int dtype)
   const int cbp = cb == 3 ? 16 : cb, ntaps = cb == 3 ? 5 : 25;
   TileSel ts = pick_tile(cb == 3 ? 32 : cbp, cs);
   const int tiles = lg_cdiv(cbp, ts.bi) * lg_cdiv(cs, ts.bj) * ntaps;
-  const int ns = pick_nsplit(tiles, B * Hm * Wm, KP);
+  const int ns = pick_nsplit(tiles, B * Hm * Wm, KP, wgrad_slots(ts.bi, ts.bj, dtype == LG_DT_BF16 && cb != 3));
   return (size_t)ns * ntaps * cbp * cs * sizeof(float);
 }
 
@@ -431,7 +447,7 @@ extern "C" int lg_conv_wgrad_m16(const float* big, const void* big16, const floa
   TileSel ts = pick_tile(patch ? 32 : p.Cbp, cs);
   const int tiles = lg_cdiv(p.Cbp, ts.bi) * lg_cdiv(cs, ts.bj) * p.ntaps;
   const int KPws = dtype == LG_DT_BF16 ? 64 : 32;  // workspace sized with the caller's dtype
-  int ns = pick_nsplit(tiles, p.M, KPws);
+  int ns = pick_nsplit(tiles, p.M, KPws, wgrad_slots(ts.bi, ts.bj, bf16));
   p.chunk = (lg_cdiv(p.M, ns) + KP - 1) / KP * KP;
   ns = lg_cdiv(p.M, p.chunk);
   hipStream_t st = (hipStream_t)stream;
