@@ -211,7 +211,8 @@ class Decoder(_ConvStack):
         if add[0] is not None:  # tiny (init_dim^2 x conv_filter[0]); later skips are fused into the norm-apply pass
             x = x + (torch.cat(add[0], 0) if isinstance(add[0], tuple) else add[0])
         m16 = self.dtype == DT_BF16
-        x16 = None
+        # level 1's input (dense + norm output, plus the first skip) is tiny: its bf16 mirror is a plain cast
+        x16 = x.to(torch.bfloat16) if m16 else None
         for i, (cb, cs) in enumerate(self.chans, 1):
             gm, bt = self._w[f"norm{i}.gamma"], self._w[f"norm{i}.beta"]
             z, st = ops.convT_s2_fwd_stats(x, packs[i - 1], self._w[f"conv{i}.bias"], cb, self.dtype, gm, bt, x16=x16)
