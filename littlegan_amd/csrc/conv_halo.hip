@@ -51,6 +51,7 @@ struct HaloParams {
   int res_budget;              // LDS bytes the resident-halo (RES) variant may use; 0 = variant off
   int cfg;                     // tile-shape switches (LG_CFG env, A/B)
   int* nparts_host;            // host-side: receives nparts of the launched tiling (moments epilogue on)
+  int epi_rows;                // rows per pass of the LDS-transposed epilogue (0 = straight from the accumulators)
 };
 
 template <typename T> struct DT;
@@ -374,6 +375,55 @@ __global__ __launch_bounds__(256, (W3 ? 3 : 2)) void conv_halo_kernel(const Halo
     }
 
     // ---- epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----------
+    // TEPI: the block's waves own column slices of the same pixel rows, so straight from the accumulators a pixel row
+    // (N x 4 B) would leave as WAVES_N separate 128-B pieces at different times.  The finished tile goes through the
+    // (now dead) halo region of LDS instead, epi_rows rows at a time, and leaves as whole rows, 16 B per lane.
+    constexpr bool TEPI = WAVES_N > 1 && !DBUF && !RES;
+    bool tepi_done = false;
+    if constexpr (TEPI) {
+      if (p.epi_rows > 0) {
+        tepi_done = true;
+        constexpr int CP = BN + 4;  // row pitch (floats)
+        float* C = reinterpret_cast<float*>(sH);
+        const int RP = p.epi_rows;  // 32 or 64
+        for (int pass = 0; pass < BM / RP; ++pass) {
+          __syncthreads();  // halo (first pass) / previous pass fully consumed
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const int fr0 = (wm * MT + i) * 32;
+            if (fr0 / RP == pass) {
+#pragma unroll
+              for (int j = 0; j < NT; ++j) {
+                const int cl = (wn * NT + j) * 32 + r, col = n0 + cl;
+                const float bv = (col < p.N && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                  float v = acc[i][j][e] + bv;
+                  if (p.act == 1) v = tanhf(v);
+                  C[(fr0 % RP + (e & 3) + 8 * (e >> 2) + 4 * h) * CP + cl] = v;
+                }
+              }
+            }
+          }
+          __syncthreads();
+          for (int idx = tid; idx < RP * (BN / 4); idx += 256) {
+            const int row = idx / (BN / 4), c4 = idx - row * (BN / 4);
+            const int o = so[pass * RP + row], col = n0 + c4 * 4;
+            if (o >= 0 && col < p.N && !(p.dbg & 16)) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(C + row * CP + c4 * 4);
+              if (p.out16) {
+                bf16x4 w;
+                w[0] = (__bf16)v[0]; w[1] = (__bf16)v[1]; w[2] = (__bf16)v[2]; w[3] = (__bf16)v[3];
+                *reinterpret_cast<bf16x4*>(p.out16 + (long long)o * p.N + col) = w;
+              } else {
+                *reinterpret_cast<f32x4*>(p.out + (long long)o * p.N + col) = v;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (!tepi_done)
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = n0 + (wn * NT + j) * 32 + r;
@@ -461,6 +511,14 @@ int launch(HaloParams p, hipStream_t st) {
     if ((NU + min_taps - 2) / (min_taps - 1) > 4) return LG_ERR_UNSUPPORTED;
   }
   p.ntn = p.Npad / BN;
+  {  // LDS-transposed epilogue: needs N % 4 == 0 and epi_rows x (BN + 4) floats inside the halo region
+    const size_t halo_bytes = (size_t)p.nrows * ROWB;
+    p.epi_rows = 0;
+    if (WAVES_N > 1 && !DBUF && !RES && p.N % 4 == 0 && !(p.cfg & 64)) {
+      if (halo_bytes >= (size_t)64 * (BN + 4) * 4) p.epi_rows = 64;
+      else if (halo_bytes >= (size_t)32 * (BN + 4) * 4) p.epi_rows = 32;
+    }
+  }
   p.nparts = (MODE == MODE_UP ? 4 : 1) * p.tpi * p.ntn;
   if (p.nparts_host) *p.nparts_host = p.nparts;
   const int ntm = p.NI == 1 ? p.B * p.tpi : lg_cdiv(p.B, p.NI);
