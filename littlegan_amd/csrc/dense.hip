@@ -45,14 +45,14 @@ __global__ __launch_bounds__(256) void dense_wgrad_kernel(const float* __restric
   extern __shared__ float xs[];  // [BT][KT] batch tile
   constexpr int BT = 64;
   const int k0 = blockIdx.y * KT;
-  const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int n = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   f32x4 acc[KT];
   f32x4 accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < KT; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int bb = 0; bb < B; bb += BT) {
     __syncthreads();
-    for (int i = threadIdx.x; i < BT * KT; i += 256) {
+    for (int i = threadIdx.x; i < BT * KT; i += blockDim.x) {
       const int b = i / KT, k = i - b * KT;
       xs[i] = (bb + b < B && k0 + k < K) ? x[(long long)(bb + b) * K + k0 + k] : 0.f;
     }
@@ -112,8 +112,9 @@ extern "C" int lg_dense_wgrad(const float* x, const float* dy, float* dw, float*
   LG_CHECK_ARG(x && dy && dw, "lg_dense_wgrad: null pointer");
   LG_CHECK_ARG(B > 0 && K > 0 && N > 0 && N % 4 == 0, "lg_dense_wgrad: bad shape B=%d K=%d N=%d", B, K, N);
   constexpr int KT = 16;
-  dim3 grid(lg_cdiv(N, 1024), lg_cdiv(K, KT));
-  hipLaunchKernelGGL(dense_wgrad_kernel<KT>, grid, dim3(256), 64 * KT * sizeof(float), (hipStream_t)stream, x, dy, dw,
+  // one wave per block (256 columns): N = 24576 gives 96 x 9 blocks; 256-thread blocks left two thirds of the CUs idle
+  dim3 grid(lg_cdiv(N, 256), lg_cdiv(K, KT));
+  hipLaunchKernelGGL(dense_wgrad_kernel<KT>, grid, dim3(64), 64 * KT * sizeof(float), (hipStream_t)stream, x, dy, dw,
                      db, B, K, N, accumulate);
   LG_CHECK_LAUNCH("lg_dense_wgrad");
   return LG_OK;
