@@ -38,58 +38,67 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------- dense wgrad (small K)
+// dw[k][n] = sum_b x[b][k] dy[b][n], db[n] = sum_b dy[b][n].  Block = 256 columns (a lane owns 4) x KT rows of dw; its
+// 4 waves split the BATCH (the per-thread chain of dependent 8-load rounds over b is what bounds this kernel, not
+// bandwidth) and merge in wave order through LDS (deterministic).
 template <int KT>
 __global__ __launch_bounds__(256) void dense_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           float* __restrict__ dw, float* __restrict__ db, int B, int K,
                                                           int N, int accumulate) {
-  extern __shared__ float xs[];  // [BT][KT] batch tile
-  constexpr int BT = 64;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* xs = sm;                       // [B][KT] the K-slice of x for the whole batch
+  f32x4* red = reinterpret_cast<f32x4*>(sm + ((B * KT + 3) / 4) * 4);  // [KT + 1][64] merge buffer
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int k0 = blockIdx.y * KT;
-  const int n = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int n = (blockIdx.x * 64 + lane) * 4;
+  for (int i = threadIdx.x; i < B * KT; i += 256) {
+    const int b = i / KT, k = i - b * KT;
+    xs[i] = (k0 + k < K) ? x[(long long)b * K + k0 + k] : 0.f;
+  }
+  __syncthreads();
   f32x4 acc[KT];
   f32x4 accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < KT; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int bb = 0; bb < B; bb += BT) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < BT * KT; i += blockDim.x) {
-      const int b = i / KT, k = i - b * KT;
-      xs[i] = (bb + b < B && k0 + k < K) ? x[(long long)(bb + b) * K + k0 + k] : 0.f;
-    }
-    __syncthreads();
-    if (n < N) {
-      const int be = min(BT, B - bb);
-      int b = 0;
-      for (; b + 8 <= be; b += 8) {  // 8 independent 16-B loads in flight per thread
-        f32x4 dv[8];
+  const int bq = (B + 3) / 4, bs = wid * bq, be = min(B, bs + bq);
+  if (n < N) {
+    int b = bs;
+    for (; b + 8 <= be; b += 8) {  // 8 independent 16-B loads in flight per thread
+      f32x4 dv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) dv[u] = *reinterpret_cast<const f32x4*>(dy + (long long)(bb + b + u) * N + n);
+      for (int u = 0; u < 8; ++u) dv[u] = *reinterpret_cast<const f32x4*>(dy + (long long)(b + u) * N + n);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          accb += dv[u];
+      for (int u = 0; u < 8; ++u) {
+        accb += dv[u];
 #pragma unroll
-          for (int k = 0; k < KT; ++k) acc[k] += xs[(b + u) * KT + k] * dv[u];
-        }
-      }
-      for (; b < be; ++b) {
-        const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + (long long)(bb + b) * N + n);
-        accb += dv;
-#pragma unroll
-        for (int k = 0; k < KT; ++k) acc[k] += xs[b * KT + k] * dv;
+        for (int k = 0; k < KT; ++k) acc[k] += xs[(b + u) * KT + k] * dv[u];
       }
     }
+    for (; b < be; ++b) {
+      const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + (long long)b * N + n);
+      accb += dv;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) acc[k] += xs[b * KT + k] * dv;
+    }
+  }
+  for (int w = 0; w < 4; ++w) {
+    if (wid == w) {
+#pragma unroll
+      for (int k = 0; k < KT; ++k) red[k * 64 + lane] = (w == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : red[k * 64 + lane]) + acc[k];
+      red[KT * 64 + lane] = (w == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : red[KT * 64 + lane]) + accb;
+    }
+    __syncthreads();
   }
   if (n >= N) return;
-#pragma unroll
-  for (int k = 0; k < KT; ++k) {
+  for (int k = wid; k < KT; k += 4) {
     if (k0 + k < K) {
       f32x4* o = reinterpret_cast<f32x4*>(dw + (long long)(k0 + k) * N + n);
-      *o = accumulate ? (*o + acc[k]) : acc[k];
+      *o = accumulate ? (*o + red[k * 64 + lane]) : red[k * 64 + lane];
     }
   }
-  if (blockIdx.y == 0 && db) {
+  if (blockIdx.y == 0 && db && wid == 0) {
     f32x4* o = reinterpret_cast<f32x4*>(db + n);
-    *o = accumulate ? (*o + accb) : accb;
+    *o = accumulate ? (*o + red[KT * 64 + lane]) : red[KT * 64 + lane];
   }
 }
 
@@ -112,10 +121,15 @@ extern "C" int lg_dense_wgrad(const float* x, const float* dy, float* dw, float*
   LG_CHECK_ARG(x && dy && dw, "lg_dense_wgrad: null pointer");
   LG_CHECK_ARG(B > 0 && K > 0 && N > 0 && N % 4 == 0, "lg_dense_wgrad: bad shape B=%d K=%d N=%d", B, K, N);
   constexpr int KT = 16;
-  // one wave per block (256 columns): N = 24576 gives 96 x 9 blocks; 256-thread blocks left two thirds of the CUs idle
+  const size_t lds = ((size_t)((B * KT + 3) / 4) * 4 + (size_t)(KT + 1) * 64 * 4) * sizeof(float);
+  LG_CHECK_ARG(lds <= 160 * 1024, "lg_dense_wgrad: batch %d too large for the LDS staging of x", B);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_wgrad_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
   dim3 grid(lg_cdiv(N, 256), lg_cdiv(K, KT));
-  hipLaunchKernelGGL(dense_wgrad_kernel<KT>, grid, dim3(64), 64 * KT * sizeof(float), (hipStream_t)stream, x, dy, dw,
-                     db, B, K, N, accumulate);
+  hipLaunchKernelGGL(dense_wgrad_kernel<KT>, grid, dim3(256), lds, (hipStream_t)stream, x, dy, dw, db, B, K, N, accumulate);
   LG_CHECK_LAUNCH("lg_dense_wgrad");
   return LG_OK;
 }
