@@ -80,31 +80,55 @@ __global__ __launch_bounds__(256) void heads_final_kernel(const float* __restric
   p[i] = 1.f / (1.f + expf(-z));
 }
 
+// dx[b][k] = dz[b][0] wpr[k] + sum_j dz[b][1+j] wc[k][j]: thread per k, DB samples per block.  The weight rows of the
+// block's 256 k's are one contiguous 256*c run: staged through LDS with coalesced loads (a thread reading its own row
+// straight from global is a 4*c-byte stride across lanes), then read back at an odd row pitch (conflict-free).
+constexpr int DB = 16;
 __global__ __launch_bounds__(256) void heads_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ wpr,
                                                           const float* __restrict__ wc, float* __restrict__ dx, int B,
                                                           int K, int c) {
-  constexpr int TB = 8;
-  __shared__ float sdz[TB][HC_MAX + 1];
-  const int b0 = blockIdx.y * TB;
-  for (int i = threadIdx.x; i < TB * (c + 1); i += 256) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  const int cp = c | 1;            // odd row pitch: the per-thread row reads are conflict-free
+  float* sw = dsm;                 // [256][cp]
+  float* sdz = dsm + ((256 * cp + 3) / 4) * 4;  // [c + 1][DB] (transposed: the DB values of one j are 4 ds_read_b128)
+  const int b0 = blockIdx.y * DB, k0 = blockIdx.x * 256;
+  const int kn = min(256, K - k0);
+  {  // flat coalesced copy; (row, col) of element i advance incrementally (no division per element)
+    const int dq = 256 / c, dr = 256 - dq * c;
+    int row = threadIdx.x / c, col = threadIdx.x - row * c;
+    for (int i = threadIdx.x; i < kn * c; i += 256) {
+      sw[row * cp + col] = wc[(long long)k0 * c + i];
+      row += dq; col += dr;
+      if (col >= c) { col -= c; ++row; }
+    }
+  }
+  for (int i = threadIdx.x; i < DB * (c + 1); i += 256) {
     const int b = i / (c + 1), j = i - b * (c + 1);
-    sdz[b][j] = (b0 + b < B) ? dz[(long long)(b0 + b) * (c + 1) + j] : 0.f;
+    sdz[j * DB + b] = (b0 + b < B) ? dz[(long long)(b0 + b) * (c + 1) + j] : 0.f;
   }
   __syncthreads();
-  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int k = k0 + threadIdx.x;
   if (k >= K) return;
-  float acc[TB];
+  float acc[DB];
   const float wp = wpr[k];
 #pragma unroll
-  for (int b = 0; b < TB; ++b) acc[b] = sdz[b][0] * wp;
-  const float* wr = wc + (long long)k * c;
+  for (int q = 0; q < DB / 4; ++q) {
+    const f32x4 d = *reinterpret_cast<const f32x4*>(sdz + q * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[q * 4 + e] = d[e] * wp;
+  }
+  const float* wr = sw + threadIdx.x * cp;
   for (int j = 0; j < c; ++j) {
     const float wv = wr[j];
 #pragma unroll
-    for (int b = 0; b < TB; ++b) acc[b] += sdz[b][1 + j] * wv;
+    for (int q = 0; q < DB / 4; ++q) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(sdz + (1 + j) * DB + q * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[q * 4 + e] += d[e] * wv;
+    }
   }
 #pragma unroll
-  for (int b = 0; b < TB; ++b)
+  for (int b = 0; b < DB; ++b)
     if (b0 + b < B) dx[(long long)(b0 + b) * K + k] = acc[b];
 }
 
@@ -193,8 +217,9 @@ extern "C" int lg_heads_dgrad(const float* dz, const float* wpr, const float* wc
                               void* stream) {
   LG_CHECK_ARG(dz && wpr && wc && dx, "lg_heads_dgrad: null pointer");
   LG_CHECK_ARG(B > 0 && K > 0 && c >= 1 && c <= HC_MAX, "lg_heads_dgrad: bad shape B=%d K=%d c=%d", B, K, c);
-  dim3 grid(lg_cdiv(K, 256), lg_cdiv(B, 8));
-  hipLaunchKernelGGL(heads_dgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, wpr, wc, dx, B, K, c);
+  dim3 grid(lg_cdiv(K, 256), lg_cdiv(B, DB));
+  const size_t lds = (size_t)((256 * (c | 1) + 3) / 4 * 4 + DB * (c + 1)) * sizeof(float);
+  hipLaunchKernelGGL(heads_dgrad_kernel, grid, dim3(256), lds, (hipStream_t)stream, dz, wpr, wc, dx, B, K, c);
   LG_CHECK_LAUNCH("lg_heads_dgrad");
   return LG_OK;
 }

@@ -15,13 +15,13 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void bce_heads_kernel(const float* __restrict__ p, const float* __restrict__ t_c,
+__global__ __launch_bounds__(1024) void bce_heads_kernel(const float* __restrict__ p, const float* __restrict__ t_c,
                                                         float t_pr, float w_pr, float w_c, float* __restrict__ loss,
                                                         float* __restrict__ dz, int B, int c, int accumulate) {
   const int J = c + 1, n = B * J;
   const float s_pr = w_pr / (float)B, s_c = w_c / (float)(B * c);
   float acc = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {  // one block (the loss is ONE scalar): 1024 threads, <= 21 trips at B=512
     const int b = i / J, j = i - b * J;
     const float sc = j == 0 ? s_pr : s_c;
     float g = 0.f;
@@ -115,7 +115,7 @@ extern "C" int lg_bce_heads_loss_fwd_bwd(const float* p, const float* t_c, float
   LG_CHECK_ARG(p && loss && dz, "lg_bce_heads_loss_fwd_bwd: null pointer");
   LG_CHECK_ARG(B > 0 && c >= 1, "lg_bce_heads_loss_fwd_bwd: bad shape B=%d c=%d", B, c);
   LG_CHECK_ARG(t_c || w_c == 0.f, "lg_bce_heads_loss_fwd_bwd: t_c is null but w_c != 0");
-  hipLaunchKernelGGL(bce_heads_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, t_c, t_pr, w_pr, w_c, loss, dz, B,
+  hipLaunchKernelGGL(bce_heads_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, t_c, t_pr, w_pr, w_c, loss, dz, B,
                      c, accumulate);
   LG_CHECK_LAUNCH("lg_bce_heads_loss_fwd_bwd");
   return LG_OK;
