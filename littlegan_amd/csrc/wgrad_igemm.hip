@@ -26,12 +26,16 @@ struct WgradParams {
   int pstride, ppad;
 };
 
+// pixels per k tile.  The 128x128 bf16 tile from the mirrors uses 32 (two MFMA k steps per barrier): its double-buffered
+// operand image is then 34.8 KB instead of 69.6 KB and THREE blocks stay resident per CU (168 VGPRs) instead of two.
+constexpr int wg_kp(bool bf16, bool src16, int mtnt) { return bf16 ? ((src16 && mtnt == 4) ? 32 : 64) : 32; }
+
 template <bool BF16, bool PATCH, bool SRC16, int WI, int WJ, int MT, int NT>
 __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p) {
   static_assert(!SRC16 || (BF16 && !PATCH), "bf16 sources only for the bf16 MFMA, non-patch kernel");
   constexpr int NTHR = 64 * WI * WJ;
   constexpr int BI = WI * MT * 32, BJ = WJ * NT * 32;
-  constexpr int KP = BF16 ? 64 : 32;           // pixels per k tile
+  constexpr int KP = wg_kp(BF16, SRC16, MT * NT);  // pixels per k tile
   constexpr int ESZ = BF16 ? 2 : 4;
   constexpr int RSA = BI * ESZ + (BF16 ? 16 : 0);   // LDS row strides (bytes)
   constexpr int RSB = BJ * ESZ + (BF16 ? 16 : 0);
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 
 template <bool BF16, bool PATCH, bool SRC16, int WI, int WJ, int MT, int NT>
 void launch_wgrad(WgradParams p, int nsplit, hipStream_t st) {
-  constexpr int BI = WI * MT * 32, BJ = WJ * NT * 32, KP = BF16 ? 64 : 32, ESZ = BF16 ? 2 : 4;
+  constexpr int BI = WI * MT * 32, BJ = WJ * NT * 32, KP = wg_kp(BF16, SRC16, MT * NT), ESZ = BF16 ? 2 : 4;
   constexpr int RSA = BI * ESZ + (BF16 ? 16 : 0), RSB = BJ * ESZ + (BF16 ? 16 : 0);
   const size_t lds = 2 * (size_t)KP * (RSA + RSB);
   p.nti = lg_cdiv(p.Cbp, BI);
@@ -360,9 +364,11 @@ inline TileSel pick_tile(int cbp, int cs) {
 
 // resident block slots of the whole chip for a tile shape (LDS-limited: 2 buffers of KP x (BI + BJ) operand rows)
 inline int wgrad_slots(int bi, int bj, bool bf16_kernel) {
-  const int KP = bf16_kernel ? 64 : 32, ESZ = bf16_kernel ? 2 : 4, padb = bf16_kernel ? 16 : 0;
+  const int KP = (bf16_kernel && bi == 128 && bj == 128) ? 32 : (bf16_kernel ? 64 : 32);  // wg_kp (mirror path assumed)
+  const int ESZ = bf16_kernel ? 2 : 4, padb = bf16_kernel ? 16 : 0;
   const size_t lds = 2 * (size_t)KP * ((bi * ESZ + padb) + (bj * ESZ + padb));
   int per_cu = (int)((160 * 1024) / lds);
+  if (bf16_kernel && bi == 128 && bj == 128 && per_cu > 3) per_cu = 3;  // 168 VGPRs
   if (per_cu > 8) per_cu = 8;
   if (per_cu < 1) per_cu = 1;
   return 256 * per_cu;
