@@ -217,6 +217,113 @@ __global__ __launch_bounds__(256) void n3_wgrad_kernel(const float* __restrict__
     *reinterpret_cast<f32x4*>(o + i * 4) = *reinterpret_cast<const f32x4*>(sB + i * 4);
 }
 
+// bf16 path of the same contraction: small = bf16 mirror, staged verbatim as [pixel][channel] bf16 and read as MFMA B
+// operands with ds_read_b64_tr_b16 (k = pixel is the row index); the 3-channel operand is gathered from the fp32 halo
+// as 8 consecutive pixels per lane and rounded to bf16 (RNE) — v_mfma_f32_32x32x16_bf16, 16 pixels per instruction
+// instead of 2, fp32 accumulate.  A k step = one tile row of 16 pixels; wave w owns tile rows 2w and 2w+1.
+template <int NT>
+__global__ __launch_bounds__(256) void n3_wgrad16_kernel(const float* __restrict__ big3, const __bf16* __restrict__ small16,
+                                                         float* __restrict__ slab, int B, int H, int W, int s, int pad) {
+  constexpr int Cs = NT * 32, TH = 8, TW = 16;
+  constexpr int RSB = Cs * 2 + 16;                       // bytes per pixel row of sB (16-B pad)
+  constexpr int SB_BYTES = (TH * TW * RSB > 75 * Cs * 4) ? TH * TW * RSB : 75 * Cs * 4;  // also the merge buffer
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  const int HH = s * TH + 4, HW = s * TW + 4;
+  char* sB = smem16;                                       // [128][RSB] bf16
+  float* sA = reinterpret_cast<float*>(smem16 + SB_BYTES);  // [HH*HW*3] fp32 halo of the 3-channel tensor
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int tpx = W / TW, tpi = tpx * (H / TH), ntiles = B * tpi;
+  const int Hb = s * H, Wb = s * W;
+  int aoff[3];
+  bool aval[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int idx = i * 32 + r;  // (tap, c3)
+    aval[i] = idx < 75;
+    const int t = idx / 3, c3 = idx - t * 3;
+    aoff[i] = aval[i] ? ((t / 5) * HW + (t % 5)) * 3 + c3 : 0;
+  }
+  f32x16 acc[3][NT];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // ds_read_b64_tr_b16 addressing (as wgrad_igemm.hip): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3
+  const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+  const int colbase = 16 * (g & 1) + 4 * lp;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / tpi, tt = tile - n * tpi;
+    const int y0 = (tt / tpx) * TH, x0 = (tt % tpx) * TW;
+    __syncthreads();
+    for (int i = threadIdx.x; i < TH * TW * (Cs / 8); i += 256) {
+      const int pix = i / (Cs / 8), c8 = i % (Cs / 8);
+      const int yy = y0 + pix / TW, xx = x0 + pix % TW;
+      *reinterpret_cast<u32x4*>(sB + pix * RSB + c8 * 16) =
+          *reinterpret_cast<const u32x4*>(small16 + ((long long)(n * H + yy) * W + xx) * Cs + c8 * 8);
+    }
+    for (int i = threadIdx.x; i < HH * HW * 3; i += 256) {
+      const int hp = i / 3, c3 = i - hp * 3;
+      const int sy = s * y0 - pad + hp / HW, sx = s * x0 - pad + hp % HW;
+      float v = 0.f;
+      if ((unsigned)sy < (unsigned)Hb && (unsigned)sx < (unsigned)Wb) v = big3[((long long)(n * Hb + sy) * Wb + sx) * 3 + c3];
+      sA[i] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ly = 2 * wid + ks;  // tile row = the 16 pixels of this k step
+      bf16x8 a[3], b[NT];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float* ap = sA + ((s * ly) * HW + s * (8 * h)) * 3 + aoff[i];
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = aval[i] ? (__bf16)ap[e * s * 3] : (__bf16)0.f;
+        a[i] = v;
+      }
+      const int row0 = ly * TW + 8 * (g >> 1) + lq;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const char* pb = sB + row0 * RSB + (j * 32 + colbase) * 2;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb + 4 * RSB));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        b[j] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* mrg = reinterpret_cast<float*>(sB);  // merge the four waves in wave order (sB is dead), one slab per block
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wid == w) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (row < 75) {
+              float* q = mrg + row * Cs + j * 32 + r;
+              *q = (w == 0 ? 0.f : *q) + acc[i][j][e];
+            }
+          }
+    }
+  }
+  __syncthreads();
+  float* o = slab + (long long)blockIdx.x * 75 * Cs;
+  for (int i = threadIdx.x; i < 75 * Cs / 4; i += 256)
+    *reinterpret_cast<f32x4*>(o + i * 4) = *reinterpret_cast<const f32x4*>(mrg + i * 4);
+}
+
 // dw[i] (+)= sum_k slab[k][i] : 16 outputs x 16 slab groups per block, merged in group order (deterministic)
 __global__ __launch_bounds__(256) void n3_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
                                                              int nslab, int n, int accumulate) {
@@ -301,7 +408,11 @@ extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void
     a = true;
   }
   float* slab = (float*)workspace;
-  if (Cs == 32) {
+  if (s16 && !getenv("LG_N3W_F32")) {  // bf16 path: bf16 MFMA straight from the mirror
+    auto ldsz = [&](int cs) { const size_t sb = (size_t)128 * (cs * 2 + 16), mg = (size_t)75 * cs * 4; return (sb > mg ? sb : mg) + (size_t)((s * 8 + 4) * (s * 16 + 4) * 3 + 4) * 4; };
+    if (Cs == 32) hipLaunchKernelGGL((n3_wgrad16_kernel<1>), dim3(nblk), dim3(256), ldsz(32), st, big3, s16, slab, B, H, W, s, pad);
+    else hipLaunchKernelGGL((n3_wgrad16_kernel<2>), dim3(nblk), dim3(256), ldsz(64), st, big3, s16, slab, B, H, W, s, pad);
+  } else if (Cs == 32) {
     if (s16) hipLaunchKernelGGL((n3_wgrad_kernel<1, true>), dim3(nblk), dim3(256), lds, st, big3, small, s16, slab, B, H, W, s, pad);
     else hipLaunchKernelGGL((n3_wgrad_kernel<1, false>), dim3(nblk), dim3(256), lds, st, big3, small, s16, slab, B, H, W, s, pad);
   } else {
