@@ -110,13 +110,13 @@ class EagerTrainer:
         if run_adj:
             adj_in_cond = (torch.cat([c2, c1], 0) + 1.0) * 0.5
             adj_t_cond = torch.cat([c2, c1], 0)
-            adj_in_img = torch.cat([img1, fake], 0)
             adj_t_img = torch.cat([img2, img1], 0)
             ctx_a: dict = {}
             # encoder(fake) was computed by D above with the same weights: hand its 4 maps to the Adjuster
             i_d, f0 = a.init_dim, a.conv_filter[0]
             tails = [ctx_d["enc"][k][0][B:] for k in (1, 2, 3)] + [ctx_d["heads_x"][B:].view(B, i_d, i_d, f0)]
-            adj_image = A([adj_in_img, adj_in_cond], ctx_a, enc_tails=tails)
+            # Adjuster input = [img1 ; fake]: with the encoder maps of `fake` handed over, only img1 is encoded here
+            adj_image = A([img1, adj_in_cond], ctx_a, enc_tails=tails)
             ctx_d2: dict = {}
             p_a = D.forward_packed(adj_image, ctx_d2, keep_maps=False)
             dz_a = torch.empty(2 * B, 1 + c, dtype=torch.float32, device=self.device)

@@ -442,7 +442,9 @@ class Adjuster(_Module):
         if enc_tails is None:
             enc = self.encoder(image)  # no context: no tape of the step differentiates through it
         else:  # the trailing samples of `image` were already encoded by D in this step (same weights): reuse
-            enc = self.encoder(image[:image.shape[0] - enc_tails[0].shape[0]], None, tails=enc_tails)
+            # `image` holds the leading samples only (or the whole batch: then its trailing rows are the ones already encoded)
+            own = cond.shape[0] - enc_tails[0].shape[0]
+            enc = self.encoder(image[:own], None, tails=enc_tails)
         c4 = self._dn(cond.contiguous(), ctx)
         x, x16 = self.decoder([c4, enc[::-1]], ctx)
         img = self.conv(x, x16=x16)
