@@ -378,13 +378,13 @@ __global__ __launch_bounds__(256, (W3 ? 3 : 2)) void conv_halo_kernel(const Halo
     // TEPI: the block's waves own column slices of the same pixel rows, so straight from the accumulators a pixel row
     // (N x 4 B) would leave as WAVES_N separate 128-B pieces at different times.  The finished tile goes through the
     // (now dead) halo region of LDS instead, epi_rows rows at a time, and leaves as whole rows, 16 B per lane.
-    constexpr bool TEPI = WAVES_N > 1 && !DBUF && !RES;
+    constexpr bool TEPI = WAVES_N > 1 && !DBUF;  // RES: the halo stays live across the classes -> its own C region behind it
     bool tepi_done = false;
     if constexpr (TEPI) {
       if (p.epi_rows > 0) {
         tepi_done = true;
         constexpr int CP = BN + 4;  // row pitch (floats)
-        float* C = reinterpret_cast<float*>(sH);
+        float* C = reinterpret_cast<float*>(RES ? sH + (p.nrows * ROWB + 15) / 16 * 16 : sH);
         const int RP = p.epi_rows;  // 32 or 64
         for (int pass = 0; pass < BM / RP; ++pass) {
           __syncthreads();  // halo (first pass) / previous pass fully consumed
@@ -503,8 +503,10 @@ template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES, int WA
 int launch(HaloParams p, hipStream_t st) {
   constexpr int BN = WAVES_N * NT * 32;
   const int ROWB = RES ? p.Cs * DT<T>::ESZ + 16 : ((W3 && MODE == MODE_DOWN) ? KCH * 32 : KCH * 32 + 16);
-  const size_t lds = (((RES ? 4 : 1) * 128 + p.nrows) * 4 + 15) / 16 * 16 + (size_t)p.nrows * ROWB * (DBUF ? 2 : 1);
+  size_t lds = (((RES ? 4 : 1) * 128 + p.nrows) * 4 + 15) / 16 * 16 + (size_t)p.nrows * ROWB * (DBUF ? 2 : 1);
   if (lds > (size_t)(RES ? p.res_budget : LDS_BUDGET)) return LG_ERR_UNSUPPORTED;
+  const bool res_epi = RES && WAVES_N > 1 && p.N % 4 == 0 && (p.cfg & 128);  // transposed epilogue for RES too: 32 rows x (BN + 4) floats of extra LDS
+  if (res_epi) lds = (lds + 15) / 16 * 16 + (size_t)32 * (BN + 4) * 4;
   if (DBUF) {  // the interleaved prefetch must fit its register window: ceil(NU/(ntaps-1)) <= 4 with the fewest taps
     constexpr int KC = KCH * 32 / DT<T>::ESZ, RPP = 256 / (SRC16 ? KC / 8 : KC / 4);
     const int NU = (p.nrows + RPP - 1) / RPP, min_taps = MODE == MODE_UP ? 4 : 25;
@@ -518,6 +520,7 @@ int launch(HaloParams p, hipStream_t st) {
       if (halo_bytes >= (size_t)64 * (BN + 4) * 4) p.epi_rows = 64;
       else if (halo_bytes >= (size_t)32 * (BN + 4) * 4) p.epi_rows = 32;
     }
+    if (res_epi) p.epi_rows = 32;
   }
   p.nparts = (MODE == MODE_UP ? 4 : 1) * p.tpi * p.ntn;
   if (p.nparts_host) *p.nparts_host = p.nparts;
@@ -625,7 +628,7 @@ extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const voi
     if (resb < 0) { const char* e = getenv("LG_RES_KB"); resb = (e ? atoi(e) : 52) * 1024; }
     p.res_budget = resb;
     static int cfg = -1;
-    if (cfg < 0) { const char* e = getenv("LG_CFG"); cfg = e ? atoi(e) : 42; }  // measured: bits 1 (128x32 wave tiles), 3 (also for small maps with W3), 5 (W3 for UP) on
+    if (cfg < 0) { const char* e = getenv("LG_CFG"); cfg = e ? atoi(e) : 170; }  // measured: bits 1 (128x32 wave tiles), 3 (also for small maps with W3), 5 (W3 for UP), 7 (RES: transposed epilogue) on
     p.cfg = cfg;
   }
   int nparts = 0;  // set by launch<> to the partial records per sample of the tiling it chose
