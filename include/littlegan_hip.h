@@ -164,6 +164,20 @@ int lg_clip_adam_update(float* w, const float* g, float* m, float* v, long long 
 int lg_adam_advance(float* state, float b1, float b2, void* stream);
 int lg_axpby(float* y, const float* x, float a, float b, long long n, void* stream);
 
+/* ---- step inputs drawn on the device  eager_trainer.py:125-131 ------------------------ */
+/* counter-based Philox4x32-10: block i = philox(counter = offset + i, key = seed); 4 x 32 bits per block */
+int lg_philox4x32(unsigned* out, int nblocks, unsigned long long seed, unsigned long long offset, void* stream);
+/* out[i] = mean + std * N(0,1) (tf.random.normal :125); element i = normal (i & 3) of block offset + i/4 */
+int lg_randn(float* out, long long n, float mean, float std, unsigned long long seed, unsigned long long offset,
+             void* stream);
+size_t lg_augment_workspace_bytes(int B);
+/* random_flip_left_right / random_brightness / random_contrast / random_hue / + noise (:127-131) with the draws
+ * given by the caller: flip[B] bytes (may be null), brightness delta db, contrast factor cf (about the per-image,
+ * per-channel mean), hue delta dh (turns), noise_scale * N(0,1) per element (Philox block offset + pixel index) */
+int lg_augment(const float* img, float* out, int B, int H, int W, const unsigned char* flip, float db, float cf, float dh,
+               float noise_scale, unsigned long long seed, unsigned long long offset, void* workspace, size_t ws_bytes,
+               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,10 @@ SIGNATURES = {
     "lg_clip_adam_update": (I, [P, P, P, P, L, P, F, F, F, F, F, F, P]),
     "lg_adam_advance": (I, [P, F, F, P]),
     "lg_axpby": (I, [P, P, F, F, L, P]),
+    "lg_philox4x32": (I, [P, I, L, L, P]),   # seed / offset: unsigned long long in C, passed as their 64-bit pattern
+    "lg_randn": (I, [P, L, F, F, L, L, P]),
+    "lg_augment_workspace_bytes": (Z, [I]),
+    "lg_augment": (I, [P, P, I, I, I, P, F, F, F, F, L, L, P, Z, P]),
 }
 
 

@@ -151,12 +151,32 @@ class EagerTrainer:
             return None,
         if not real_cond_1.shape[0] == real_cond_2.shape[0] == self.args.batch_size:
             return False,
-        noise = torch.randn(self.args.batch_size, self.args.noise_dim, device=self.device)
-        new_image = augment(real_image_1)
+        noise, new_image = self.draw_step_inputs(real_image_1)
         inp = dict(real_image_1=real_image_1, real_cond_1=real_cond_1, real_image_2=real_image_2,
                    real_cond_2=real_cond_2, noise=noise, new_image=new_image)
         fake, adj, lg, ld, la = self.train_step_from_inputs(batch_no, inp)
         return True, fake, adj, lg, ld, la
+
+    def draw_step_inputs(self, real_image_1):
+        """eager_trainer.py:125-131 on the device: noise ~ N(0,1) and the augmented copy of the first real batch.  All
+        draws are counter-based (Philox4x32-10 keyed by args.seed and the rank; one 2^40-block counter window per step),
+        so a step's inputs can be regenerated from (seed, rank, step) alone."""
+        a = self.args
+        step = self._input_step = getattr(self, "_input_step", 0) + 1
+        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+        seed = (int(getattr(a, "seed", 0)) << 20) ^ rank
+        base = step << 40
+        noise = ops.randn((a.batch_size, a.noise_dim), seed, base, device=self.device)
+        # the scalar draws of the TF ops (one per batch) and the per-image flips: a few bytes from the block window at 2^39
+        nb = (a.batch_size + 3 + 3) // 4 + 1
+        bits = ops.philox4x32(nb, seed, base + (1 << 39), device=self.device).cpu().numpy().view("uint32")
+        u = (bits >> 8).astype("float64") / 16777216.0
+        db = (2.0 * u[0] - 1.0) * 0.02                    # random_brightness(0.02)
+        cf = 0.75 + u[1] * (1.003 - 0.75)                 # random_contrast(0.75, 1.003)
+        dh = (2.0 * u[2] - 1.0) * 0.03                    # random_hue(0.03)
+        flip = torch.tensor((u[3:3 + a.batch_size] < 0.5).astype("uint8"), device=self.device)
+        new_image = ops.augment(real_image_1.contiguous(), flip, db, cf, dh, 0.1 * 0.2, seed, base + (1 << 38))
+        return noise, new_image
 
     # ------------------------------------------------------------------ eager_trainer.py:180-229
     def _interrupted(self, signum, f_name):
@@ -306,18 +326,3 @@ class EagerTrainer:
 
     def plot(self):
         raise NotImplementedError("plot (keras plot_model / pydot) is UI tooling outside the hot path (SURVEY.md §2 row 5)")
-
-
-def augment(image: torch.Tensor) -> torch.Tensor:
-    """Input side of the step (eager_trainer.py:127-131).  The TF image ops are RNG- and kernel-specific, so
-    parity treats `new_image` as an INPUT; this is a plain torch stand-in with the same
-    structure (flip, brightness +-0.02, contrast [0.75,1.003], + 0.1*N(0,0.2)); hue is not applied."""
-    B = image.shape[0]
-    dev = image.device
-    flip = torch.rand(B, device=dev) < 0.5
-    x = torch.where(flip.view(B, 1, 1, 1), image.flip(2), image)
-    x = x + (torch.rand(B, 1, 1, 1, device=dev) * 0.04 - 0.02)
-    cf = 0.75 + torch.rand(B, 1, 1, 1, device=dev) * (1.003 - 0.75)
-    mean = x.mean(dim=(1, 2), keepdim=True)
-    x = (x - mean) * cf + mean
-    return (x + 0.1 * torch.randn_like(x) * 0.2).contiguous()

@@ -518,3 +518,41 @@ def convT_s2_fwd_stats(x, pack, bias, cb, dtype, gamma, beta, x16=None):
     st = _fwd_stats("lg_convT_s2_fwd_stats", x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, "conv_igemm_up",
                     50.0 * B * Hs * Ws * cb * cs)
     return out, st
+
+
+# ------------------------------------------------------------------ step inputs on the device (eager_trainer.py:125-131)
+def _i64(v):
+    """unsigned 64-bit value as the signed pattern ctypes' c_longlong takes"""
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def philox4x32(nblocks, seed, offset, device="cuda"):
+    out = torch.empty(nblocks * 4, dtype=torch.int32, device=device)
+    check(_lib.load().lg_philox4x32(_p(out), nblocks, _i64(seed), _i64(offset), _stream()), "lg_philox4x32")
+    return out
+
+
+def randn(shape, seed, offset, mean=0.0, std=1.0, device="cuda"):
+    """tf.random.normal(shape, mean, std) from the counter-based generator: reproducible per (seed, offset)."""
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    check(_lib.load().lg_randn(_p(out), out.numel(), float(mean), float(std), _i64(seed), _i64(offset), _stream()), "lg_randn")
+    return out
+
+
+def augment(img, flip, db, cf, dh, noise_scale, seed, offset, out=None):
+    """flip: uint8 [B] device tensor or None; see lg_augment."""
+    B, H, W, c = img.shape
+    _chk(img, name="img")
+    if c != 3:
+        raise ValueError("augment: 3-channel images only")
+    if out is None:
+        out = torch.empty_like(img)
+    _chk(out, img.shape, "out")
+    if flip is not None and not (flip.is_cuda and flip.dtype == torch.uint8 and flip.numel() == B and flip.is_contiguous()):
+        raise ValueError("augment: flip must be a contiguous uint8 CUDA tensor with B elements")
+    lib = _lib.load()
+    ws = workspace(int(lib.lg_augment_workspace_bytes(B)), img.device, "small")
+    check(lib.lg_augment(_p(img), _p(out), B, H, W, _p(flip), float(db), float(cf), float(dh), float(noise_scale),
+                         _i64(seed), _i64(offset), _p(ws), ws.numel(), _stream()), "lg_augment")
+    return out

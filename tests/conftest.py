@@ -4,8 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+for _p in (ROOT, os.path.dirname(os.path.abspath(__file__))):  # repo root (oracle, littlegan_amd) and tests/ (shared helpers)
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 
 
 def pytest_configure(config):
