@@ -1,0 +1,54 @@
+"""Fréchet-distance arithmetic of the FID pass (/root/reference/fid.py:112-163 and :185-188).
+
+Only the arithmetic: d^2 = |mu1 - mu2|^2 + tr(S1 + S2 - 2 (S1 S2)^(1/2)).  The Inception pool_3 activations it is
+normally fed with need a frozen graph that the reference downloads (fid.py:276) and this pipeline cannot obtain, so
+the entry points take activation matrices.  The O(N D^2) part (mean and covariance of [N, D] activations) runs on the
+device in fp64; the D x D matrix square root stays on the host (scipy), as in the reference."""
+import warnings
+
+import numpy as np
+import torch
+
+
+def activation_statistics(act: torch.Tensor):
+    """fid.py:185-188: mu = mean over samples, sigma = np.cov(act, rowvar=False) (divisor N - 1).  act [N, D], any
+    device; the reduction is done where the tensor lives, in float64."""
+    if act.dim() != 2 or act.shape[0] < 2:
+        raise ValueError("activation_statistics: need an [N >= 2, D] matrix")
+    a = act.to(torch.float64)
+    mu = a.mean(dim=0)
+    c = a - mu
+    sigma = (c.t() @ c) / (a.shape[0] - 1)
+    return mu.cpu().numpy(), sigma.cpu().numpy()
+
+
+def frechet_distance(mu1, sigma1, mu2, sigma2, eps: float = 1e-6) -> float:
+    """fid.py:112-163.  Same guards as the reference: a non-finite square root of the product retries with eps on both
+    diagonals (with a warning); a complex result is accepted only if its diagonal is real to 1e-3."""
+    from scipy import linalg
+    mu1, mu2 = np.atleast_1d(np.asarray(mu1, np.float64)), np.atleast_1d(np.asarray(mu2, np.float64))
+    s1, s2 = np.atleast_2d(np.asarray(sigma1, np.float64)), np.atleast_2d(np.asarray(sigma2, np.float64))
+    if mu1.shape != mu2.shape:
+        raise ValueError("frechet_distance: mean vectors have different lengths")
+    if s1.shape != s2.shape:
+        raise ValueError("frechet_distance: covariances have different dimensions")
+    root = linalg.sqrtm(s1 @ s2)
+    if isinstance(root, tuple):  # old scipy returns (sqrtm, error estimate) when disp=False; be liberal
+        root = root[0]
+    if not np.isfinite(root).all():
+        warnings.warn(f"fid calculation produces singular product; adding {eps} to diagonal of cov estimates")
+        ridge = np.eye(s1.shape[0]) * eps
+        root = linalg.sqrtm((s1 + ridge) @ (s2 + ridge))
+    if np.iscomplexobj(root):
+        if not np.allclose(np.diagonal(root).imag, 0.0, atol=1e-3):
+            raise ValueError(f"Imaginary component {np.max(np.abs(root.imag))}")
+        root = root.real
+    d = mu1 - mu2
+    return float(d @ d + np.trace(s1) + np.trace(s2) - 2.0 * np.trace(root))
+
+
+def fid_from_activations(act_a: torch.Tensor, act_b: torch.Tensor) -> float:
+    """FID between two activation sets (what evaluate.py computes once the Inception features exist)."""
+    m1, s1 = activation_statistics(act_a)
+    m2, s2 = activation_statistics(act_b)
+    return frechet_distance(m1, s1, m2, s2)

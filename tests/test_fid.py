@@ -1,0 +1,56 @@
+"""FID arithmetic (fid.py:112-163,185-188) pinned by the known answers derivable from the source:
+identical statistics -> 0, the closed form for diagonal covariances, and np.cov for the statistics."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from littlegan_amd.fid import activation_statistics, fid_from_activations, frechet_distance
+
+
+def test_identical_statistics_give_zero():
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((50, 8))
+    s = np.cov(a, rowvar=False)
+    assert abs(frechet_distance(a.mean(0), s, a.mean(0), s)) < 1e-9
+
+
+def test_diagonal_covariances_closed_form():
+    rng = np.random.default_rng(1)
+    m1, m2 = rng.standard_normal(16), rng.standard_normal(16)
+    v1, v2 = rng.uniform(0.1, 2.0, 16), rng.uniform(0.1, 2.0, 16)
+    exp = ((m1 - m2) ** 2).sum() + ((np.sqrt(v1) - np.sqrt(v2)) ** 2).sum()
+    assert abs(frechet_distance(m1, np.diag(v1), m2, np.diag(v2)) - exp) < 1e-9
+
+
+def test_statistics_match_numpy_and_shapes_are_checked():
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((200, 12)).astype(np.float32)
+    mu, sigma = activation_statistics(torch.tensor(a))
+    assert np.allclose(mu, a.astype(np.float64).mean(0)) and np.allclose(sigma, np.cov(a.astype(np.float64), rowvar=False))
+    with pytest.raises(ValueError):
+        frechet_distance(np.zeros(3), np.eye(3), np.zeros(4), np.eye(4))
+    with pytest.raises(ValueError):
+        activation_statistics(torch.zeros(1, 4))
+    b = a + 0.5
+    d = fid_from_activations(torch.tensor(a), torch.tensor(b))
+    assert abs(d - 12 * 0.25) < 1e-4      # same covariance, means shifted by 0.5 in 12 dimensions
+
+
+def test_singular_product_takes_the_ridge_path_or_stays_finite():
+    z = np.zeros((4, 4))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        d = frechet_distance(np.zeros(4), z, np.ones(4), z)
+    assert np.isfinite(d) and abs(d - 4.0) < 1e-3
+
+
+@pytest.mark.gpu
+def test_statistics_on_the_device():
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.randn(4096, 256, device="cuda", generator=g)
+    mu, sigma = activation_statistics(a)
+    an = a.double().cpu().numpy()
+    assert np.allclose(mu, an.mean(0), atol=1e-12) and np.allclose(sigma, np.cov(an, rowvar=False), atol=1e-10)
+    assert abs(fid_from_activations(a, a)) < 1e-6
