@@ -231,3 +231,33 @@ def test_checkpoint_resume_is_bit_exact(tmp_path):
     tr3 = EagerTrainer(a2, g, d, Adjuster(a2, d, g), None)
     with pytest.raises(ValueError):
         tr3.load_checkpoint(path)
+
+
+@pytest.mark.parametrize("mfma", ["f32", "bf16"])
+def test_predict_matches_oracle(tmp_path, mfma):
+    """Inference path of the trainer shell (eager_trainer.py:265-298): generator / discriminator / adjuster forwards
+    through the same kernels, the MSE metrics against soft(1) / soft(0) / cond and the x100 rounding of the saved lists."""
+    import json
+    tol = TOLS[mfma]
+    cfg = O.Cfg(init_dim=2, conv_filter=(64, 32, 32, 32, 32), cond_dim=5, noise_dim=11, batch_size=3)
+    W = perturbed(cfg, 4)
+    tr = build(cfg, W, mfma)
+    inp = f32_round(O.make_inputs(cfg, 3, seed=5))
+    noise, cond, image = inp["noise"], inp["real_cond_1"], inp["real_image_1"]
+    d = dev_inputs(inp)
+    jpath = str(tmp_path / "p.json")
+    gen, save, adj_real, adj_fake = tr.predict(d["noise"], d["real_cond_1"], d["real_image_1"], None, jpath, None)
+    g_ref, _ = O.generator_fwd(cfg, W["G"], noise, cond)
+    assert np.abs(gen.cpu().numpy() - g_ref).max() < tol["img"]
+    (rp, rc), _ = O.discriminator_fwd(cfg, W["D"], image)
+    (fp, fc), _ = O.discriminator_fwd(cfg, W["D"], g_ref)
+    mse = lambda t, p: float(((t - p) ** 2).mean(-1).mean(0))
+    for key, exp in (("real_pr_mse", mse(O.soft(1.0), rp)), ("real_c_mse", mse(cond, rc)),
+                     ("fake_pr_mse", mse(O.soft(0.0), fp)), ("fake_c_mse", mse(cond, fc))):
+        assert abs(save[key] - exp) < max(tol["loss"] * abs(exp), 1e-6), key
+    saved = json.load(open(jpath))
+    assert saved["real_cond"] == np.round(cond * 100).astype(int).tolist()
+    assert np.abs(np.array(saved["real_pr"]) - rp * 100).max() <= 0.5 + 100 * tol["img"]
+    a_ref, _ = O.adjuster_fwd(cfg, W, image, cond)
+    assert np.abs(adj_real.cpu().numpy() - a_ref).max() < tol["img"]
+    assert adj_fake.shape == adj_real.shape
