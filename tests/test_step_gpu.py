@@ -169,12 +169,16 @@ def test_golden_fixture_f32():
             assert d.mean() < 0.05 * cfg.lr * len(STEPS), (m, i, d.mean())
 
 
-@pytest.mark.parametrize("mfma,init_dim", [("f32", 4), ("bf16", 4), ("f32", 8), ("bf16", 8)])
+@pytest.mark.parametrize("mfma,init_dim", [("f32", 4), ("bf16", 4), ("f32", 8), ("bf16", 8), ("f32", 16), ("bf16", 16)])
 def test_step_full_channels_one_step(mfma, init_dim):
-    """Reference channel widths (384..32), B=2: 64x64 images (C1 shape) and 128x128 (the C2 / C3 benchmark shape, so
+    """Reference channel widths (384..32), B=2: 64x64 images (C1 shape), 128x128 (the C2 / C3 benchmark shape, so
     the exact layer geometries bench.py times are the ones checked here: resident-halo tiles, 128x32 wave tiles,
-    tap-product kernels of the 3-channel layers)."""
-    tol = TOLS[mfma]
+    tap-product kernels of the 3-channel layers) and 256x256 (the C5 geometry)."""
+    tol = dict(TOLS[mfma])
+    if mfma == "f32" and init_dim == 16:
+        # 4x more elements per map than at 128x128: more LeakyReLU pre-activations within fp32 rounding of zero flip sign
+        # (DESIGN.md par. 2; measured median gradient error 9e-5 while images / losses stay at 8e-6 / 1e-6)
+        tol["grad_med"] *= 8
     cfg = O.Cfg(init_dim=init_dim, cond_dim=40, batch_size=2)
     W = perturbed(cfg, 7)
     tr = build(cfg, W, mfma)
