@@ -27,13 +27,14 @@ if ROOT not in sys.path:
 
 PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md:41-43
 # algorithmic conv/convT/dense FLOPs per image of the per-device batch at 128^2, c=40
-GFLOP_PER_IMAGE = {"c3": 27.03, "c2": 13.25}
+GFLOP_PER_IMAGE = {"c3": 27.03, "c2": 13.25, "c5": 108.1}  # c5: 256^2
 
 
 def make_args(workload, device):
-    c3 = workload == "c3"
+    c3 = workload in ("c3", "c5")  # c5 = the C3 step at 256x256 (init_dim 16): the per-GPU share of BASELINE configs[4]
     return SimpleNamespace(
-        batch_size=256 if c3 else 64, image_channel=3, noise_dim=93, init_dim=8, conv_filter=[384, 256, 128, 64, 32],
+        batch_size=256 if c3 else 64, image_channel=3, noise_dim=93, init_dim=16 if workload == "c5" else 8,
+        conv_filter=[384, 256, 128, 64, 32],
         kernel_size=5, leaky_alpha=0.3, dropout_rate=0.5, l1_lambda=0.02, lr=5e-5, beta_1=0.5, beta_2=0.9,
         use_gp=False, use_clip=True, clip_range=0.5, use_partition=True, partition_interval=4,
         train_adj=c3, cond_dim=40, mfma_dtype="bf16" if c3 else "f32", device=device, seed=0, no_io=True)
@@ -55,7 +56,8 @@ def cpu_baseline(workload):
     from oracle import np_oracle as O
     from oracle import torch_oracle as T
     Bc = 8
-    cfg = O.Cfg(batch_size=Bc, cond_dim=40, train_adj=(workload == "c3"))
+    idim = 16 if workload == "c5" else 8
+    cfg = O.Cfg(batch_size=Bc, cond_dim=40, train_adj=(workload != "c2"), init_dim=idim)
     W = O.init_weights(cfg, 0)
     tr = T.Trainer(cfg, W, dtype=torch.float32)
     inp = {k: torch.tensor(v, dtype=torch.float32) for k, v in O.make_inputs(cfg, Bc, 1234).items()}
@@ -66,7 +68,7 @@ def cpu_baseline(workload):
         n += 1
     dt = (time.perf_counter() - t0) / n
     return {"value": round(Bc / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"torch-CPU fp32 restatement (oracle/torch_oracle.py) of the same {workload} step at 128x128, "
+            "sample": f"torch-CPU fp32 restatement (oracle/torch_oracle.py) of the same {workload} step at {idim * 16}x{idim * 16}, "
                       f"batch {Bc}, {n} timed steps, {dt:.2f} s/step, nproc={os.cpu_count()}"}
 
 
@@ -75,7 +77,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)    # >= 50 timed steps after 15 warm-up (partition steps included)
     ap.add_argument("--warmup", type=int, default=15)
-    ap.add_argument("--workload", choices=["c3", "c2"], default="c3")
+    ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -150,13 +152,15 @@ def main():
         conv_sec = sum(v[2] for v in prof.values())
         conv_fl = sum(v[1] for v in prof.values())
         out = {
-            "metric": "128x128 CelebA-shaped images/sec (G+D+Adj step)" if a.workload == "c3" else "128x128 CelebA-shaped images/sec (G+D step)",
+            "metric": {"c3": "128x128 CelebA-shaped images/sec (G+D+Adj step)", "c2": "128x128 CelebA-shaped images/sec (G+D step)",
+                       "c5": "256x256 CelebA-shaped images/sec (G+D+Adj step)"}[a.workload],
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dt_name, "data": "synthetic",
-            "config": {"workload": ("C3: 128x128x3 synthetic CelebA, batch 256/GPU, bf16 MFMA conv/transposed-conv + Adjuster branch"
-                                    if a.workload == "c3" else "C2: 128x128x3 synthetic CelebA, batch 64/GPU, exact-f32 MFMA, G+D step only"),
-                       "global_batch": gb, "per_gpu_batch": args.batch_size, "image": 128, "cond_dim": 40,
+            "config": {"workload": {"c3": "C3: 128x128x3 synthetic CelebA, batch 256/GPU, bf16 MFMA conv/transposed-conv + Adjuster branch",
+                                    "c2": "C2: 128x128x3 synthetic CelebA, batch 64/GPU, exact-f32 MFMA, G+D step only",
+                                    "c5": "C5 (per-GPU share): 256x256x3 synthetic CelebA, batch 256/GPU, bf16 MFMA + Adjuster branch"}[a.workload],
+                       "global_batch": gb, "per_gpu_batch": args.batch_size, "image": args.init_dim * 16, "cond_dim": 40,
                        "parallelism": f"dp{world}", "consumed_samples_per_step": 2 * gb},
             "roofline": {"bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": PEAK[dt_name], "unit": "TFLOP/s",
                          "frac": round(ach / PEAK[dt_name], 4), "traffic": traffic, "traffic_unit": "bytes/launch",
