@@ -87,6 +87,9 @@ def load():
         raise LittleGanHipError(
             f"{LIB_PATH} not found: build it with `python -m littlegan_amd.csrc.build` "
             "(the LittleGAN hot path has no CPU fallback)")
+    # torch first: it ships its own libamdhip64 and must be the HIP runtime of the process.  If this library were loaded
+    # before torch, the system runtime it links against would come in as a SECOND runtime and its kernels would see no device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
