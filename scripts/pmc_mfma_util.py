@@ -1,0 +1,45 @@
+"""MFMA busy fraction per kernel from a rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE pass (csv).
+
+usage: python scripts/pmc_mfma_util.py counter_collection.csv [out.md]
+MfmaUtil (rocprofv3's derived metric, gfx94x formula) = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (max(GRBM_GUI_ACTIVE) * SIMD_NUM).
+The csv carries GRBM_GUI_ACTIVE summed over the 8 XCDs, so max is taken as sum / 8; SIMD_NUM = 256 CUs x 4.
+The average shader clock during a kernel follows as (GUI_ACTIVE / 8) / duration."""
+import collections
+import csv
+import re
+import sys
+
+
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    return re.sub(r"\(.*$", "", n)[:100]
+
+
+def main():
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    disp = collections.defaultdict(dict)
+    for r in rows:
+        d = disp[r["Dispatch_Id"]]
+        d["name"] = short(r["Kernel_Name"])
+        d[r["Counter_Name"]] = float(r["Counter_Value"])
+        d["dur"] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    agg = collections.defaultdict(lambda: [0.0, 0.0, 0.0, 0])
+    for d in disp.values():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" not in d or "GRBM_GUI_ACTIVE" not in d:
+            continue
+        a = agg[d["name"]]
+        a[0] += d["SQ_VALU_MFMA_BUSY_CYCLES"]; a[1] += d["GRBM_GUI_ACTIVE"] / 8.0; a[2] += d["dur"]; a[3] += 1
+    lines = ["| kernel | launches | MFMA busy % | avg shader clock GHz | total ms |", "|---|---|---|---|---|"]
+    for name, (busy, gui, dur, n) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+        if busy <= 0:
+            continue
+        lines.append(f"| `{name}` | {n} | {100.0 * busy / (gui * 1024.0):.1f} | {gui / dur:.2f} | {dur / 1e6:.2f} |")
+    out = "\n".join(lines)
+    print(out)
+    if len(sys.argv) > 2:
+        open(sys.argv[2], "w").write(out + "\n\nSource: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -- python bench.py "
+                                     "--steps 2 --warmup 1 --no-cpu-baseline (counter pass serialises kernels; durations are longer than in the timed run).\n")
+
+
+if __name__ == "__main__":
+    main()
