@@ -29,6 +29,12 @@ struct WgradParams {
 // pixels per k tile.  The 128x128 bf16 tile from the mirrors uses 32 (two MFMA k steps per barrier): its double-buffered
 // operand image is then 34.8 KB instead of 69.6 KB and THREE blocks stay resident per CU (168 VGPRs) instead of two.
 constexpr int wg_kp(bool bf16, bool src16, int mtnt) { return bf16 ? ((src16 && mtnt == 4) ? 32 : 64) : 32; }
+// LDS row stride (bytes) of a [pixel][channels] bf16 operand image read with ds_read_b64_tr_b16: a 32-lane group reads
+// 4 consecutive rows x 64 B (16 banks) each, so the rows must sit 16 banks apart: stride = 64 or 192 (mod 256).  The
+// former 16-B pad left them 4 banks apart (measured: SQ_LDS_BANK_CONFLICT = 60 % of the LDS-active cycles).
+// Measured: the 128x128 tile 251 -> 228 us with the 64-B pad; the smaller tiles got SLOWER with it (less LDS headroom,
+// store conflicts), so they keep the 16-B pad.
+constexpr int wg_rs(bool bf16, int ch, bool sq128) { return bf16 ? (sq128 ? ch * 2 + 64 : ch * 2 + 16) : ch * 4; }
 
 template <bool BF16, bool PATCH, bool SRC16, int WI, int WJ, int MT, int NT>
 __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p) {
@@ -36,9 +42,8 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_kernel(const WgradParams p
   constexpr int NTHR = 64 * WI * WJ;
   constexpr int BI = WI * MT * 32, BJ = WJ * NT * 32;
   constexpr int KP = wg_kp(BF16, SRC16, MT * NT);  // pixels per k tile
-  constexpr int ESZ = BF16 ? 2 : 4;
-  constexpr int RSA = BI * ESZ + (BF16 ? 16 : 0);   // LDS row strides (bytes)
-  constexpr int RSB = BJ * ESZ + (BF16 ? 16 : 0);
+  constexpr int RSA = wg_rs(BF16, BI, BI == 128 && BJ == 128);   // LDS row strides (bytes)
+  constexpr int RSB = wg_rs(BF16, BJ, BI == 128 && BJ == 128);
   constexpr int LA = SRC16 ? BI / 8 : BI / 4, LB = SRC16 ? BJ / 8 : BJ / 4;  // 16-B lanes per row
   static_assert(NTHR % LA == 0 && NTHR % LB == 0, "staging geometry");
   constexpr int RA = NTHR / LA, RB = NTHR / LB;  // rows per pass
@@ -338,8 +343,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 
 template <bool BF16, bool PATCH, bool SRC16, int WI, int WJ, int MT, int NT>
 void launch_wgrad(WgradParams p, int nsplit, hipStream_t st) {
-  constexpr int BI = WI * MT * 32, BJ = WJ * NT * 32, KP = wg_kp(BF16, SRC16, MT * NT), ESZ = BF16 ? 2 : 4;
-  constexpr int RSA = BI * ESZ + (BF16 ? 16 : 0), RSB = BJ * ESZ + (BF16 ? 16 : 0);
+  constexpr int BI = WI * MT * 32, BJ = WJ * NT * 32, KP = wg_kp(BF16, SRC16, MT * NT);
+  constexpr int RSA = wg_rs(BF16, BI, BI == 128 && BJ == 128), RSB = wg_rs(BF16, BJ, BI == 128 && BJ == 128);
   const size_t lds = 2 * (size_t)KP * (RSA + RSB);
   p.nti = lg_cdiv(p.Cbp, BI);
   p.ntj = lg_cdiv(p.Cs, BJ);
@@ -365,8 +370,8 @@ inline TileSel pick_tile(int cbp, int cs) {
 // resident block slots of the whole chip for a tile shape (LDS-limited: 2 buffers of KP x (BI + BJ) operand rows)
 inline int wgrad_slots(int bi, int bj, bool bf16_kernel) {
   const int KP = (bf16_kernel && bi == 128 && bj == 128) ? 32 : (bf16_kernel ? 64 : 32);  // wg_kp (mirror path assumed)
-  const int ESZ = bf16_kernel ? 2 : 4, padb = bf16_kernel ? 16 : 0;
-  const size_t lds = 2 * (size_t)KP * ((bi * ESZ + padb) + (bj * ESZ + padb));
+  const bool sq = bi == 128 && bj == 128;
+  const size_t lds = 2 * (size_t)KP * (wg_rs(bf16_kernel, bi, sq) + wg_rs(bf16_kernel, bj, sq));
   int per_cu = (int)((160 * 1024) / lds);
   if (bf16_kernel && bi == 128 && bj == 128 && per_cu > 3) per_cu = 3;  // 168 VGPRs
   if (per_cu > 8) per_cu = 8;
