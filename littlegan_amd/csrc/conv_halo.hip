@@ -44,6 +44,7 @@ struct HaloParams {
   int ntn;
   int TH, TW, NI, tpi_x, tpi;  // tile geometry: tiles per image along x, tiles per image
   int HH, HW, HROWS, nrows;    // halo geometry (per image) and total halo rows
+  int HWH, HWP;                // W3 / DOWN: half and full pitch (pixels) of a de-interleaved halo pixel row
   int dbg;                     // ablation switches for scripts/bench_layer.py (LG_DBG env; 0 in production)
   double* spart;               // fused InstanceNorm moments: [B][nparts][3] = {count, mean, M2} per block, or null
   int nparts;
@@ -159,10 +160,19 @@ __global__ __launch_bounds__(256, (W3 ? 3 : 2)) void conv_halo_kernel(const Halo
   }
   for (int hr = tid; hr < p.nrows; hr += 256) {
     const int i = hr / p.HROWS, rem = hr - i * p.HROWS;
-    const int hy = rem / p.HW, hx = rem - hy * p.HW;
+    int hy, hx;
+    bool hv = true;
+    if constexpr (SWZ) {  // de-interleaved image: a halo pixel row holds its even columns, then its odd columns (HWH each)
+      hy = rem / p.HWP;
+      const int hxp = rem - hy * p.HWP;
+      hx = hxp < p.HWH ? 2 * hxp : 2 * (hxp - p.HWH) + 1;
+      hv = hx < p.HW;
+    } else {
+      hy = rem / p.HW; hx = rem - hy * p.HW;
+    }
     const int n = img0 + i, sy = SS * y0 + LO + hy, sx = SS * x0 + LO + hx;
     int o = -1;
-    if (n < p.B && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws) o = (n * p.Hs + sy) * p.Ws + sx;
+    if (hv && n < p.B && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws) o = (n * p.Hs + sy) * p.Ws + sx;
     s_hoff[hr] = o;
   }
   // per-lane halo base row of the MT fragments this wave reads
@@ -172,7 +182,8 @@ __global__ __launch_bounds__(256, (W3 ? 3 : 2)) void conv_halo_kernel(const Halo
     const int m = (wm * MT + i) * 32 + pix32(r);
     const int ii = m / THW, rem = m - ii * THW;
     const int ly = rem / p.TW, lx = rem - ly * p.TW;
-    hb[i] = ii * p.HROWS + (SS * ly - LO) * p.HW + SS * lx - LO;
+    if constexpr (SWZ) hb[i] = ii * p.HROWS + 2 * ly * p.HWP + lx;  // tap (ky, kx) adds ky*HWP + (kx>>1) + (kx&1)*HWH
+    else hb[i] = ii * p.HROWS + (SS * ly - LO) * p.HW + SS * lx - LO;
   }
 
   int ntaps;
@@ -258,7 +269,9 @@ __global__ __launch_bounds__(256, (W3 ? 3 : 2)) void conv_halo_kernel(const Halo
     const int cc = it / ntaps, t = it - cc * ntaps;
     int dy, dx, widx;
     tap_info(MODE, cls, t, dy, dx, widx);
-    const int toff = dy * p.HW + dx;
+    // SWZ (DOWN): stride-2 columns are consecutive rows of the de-interleaved image -> a ds_read_b128 lane group (16
+    // consecutive pixels of a tile row) reads 16 consecutive 64-B rows = 16 distinct slots with the (row>>2)&3 XOR
+    const int toff = SWZ ? (dy + 1) * p.HWP + ((dx + 1) >> 1) + ((dx + 1) & 1) * p.HWH : dy * p.HW + dx;
     if constexpr (RES) sH += cc * (KCH * 32);  // this chunk's channels inside the resident row
 #pragma unroll
     for (int q = 0; q < KCH; ++q) {
@@ -517,6 +530,10 @@ constexpr int LDS_BUDGET = 80 * 1024;  // two blocks per CU (160 KiB)
 template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES, int WAVES_M, int WAVES_N, int MT, int NT, bool W3 = false>
 int launch(HaloParams p, hipStream_t st) {
   constexpr int BN = WAVES_N * NT * 32;
+  if (W3 && MODE == MODE_DOWN) {  // de-interleaved halo pixel rows (even columns, then odd columns)
+    p.HWH = (p.HW + 1) / 2; p.HWP = 2 * p.HWH;
+    p.HROWS = p.HH * p.HWP; p.nrows = p.NI * p.HROWS;
+  }
   const int ROWB = RES ? p.Cs * DT<T>::ESZ + 16 : ((W3 && MODE == MODE_DOWN) ? KCH * 32 : KCH * 32 + 16);
   size_t lds = (((RES ? 4 : 1) * 128 + p.nrows) * 4 + 15) / 16 * 16 + (size_t)p.nrows * ROWB * (DBUF ? 2 : 1);
   if (lds > (size_t)(RES ? p.res_budget : LDS_BUDGET)) return LG_ERR_UNSUPPORTED;
