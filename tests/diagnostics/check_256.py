@@ -1,8 +1,8 @@
 """One full-channel step at 256x256 (C5 layer geometry, init_dim=16, B=2) against the fp64 oracle: images, losses and
 gradients with the tolerances of tests/test_step_gpu.py.  Manual check (the oracle step takes ~1 min of CPU)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np
 from oracle import np_oracle as O
 from test_step_gpu import TOLS, build, check_grads, dev_inputs, f32_round, perturbed

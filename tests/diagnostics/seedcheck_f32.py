@@ -1,7 +1,7 @@
 """Gradient error of one f32 step at 128x128 (full channels, B=2) against the fp64 oracle for several input seeds:
 shows the LeakyReLU sign-flip sensitivity the tolerances of tests/test_step_gpu.py account for."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from oracle import np_oracle as O

@@ -178,7 +178,7 @@ def test_step_full_channels_one_step(mfma, init_dim):
     if mfma == "f32" and init_dim >= 8:
         # At these sizes a step evaluates ~2e7 LeakyReLU pre-activations; the ones closest to zero (|v| ~ 1e-7) sit inside
         # fp32 rounding, so whether one flips sign against the fp64 oracle depends on summation order — and ONE flip moves
-        # a tape's gradients by ~1e-3 (DESIGN.md par. 2; scripts/seedcheck_f32.py: medians 2e-6 / 4e-6 / 4e-4 / 2e-3 over
+        # a tape's gradients by ~1e-3 (DESIGN.md par. 2; tests/diagnostics/seedcheck_f32.py: medians 2e-6 / 4e-6 / 4e-4 / 2e-3 over
         # four input seeds of the same build).  Images and losses stay at 1e-5 / 1e-6; the strict gradient bound is kept
         # at 64x64 and in the per-op tests, here the median only has to stay under the per-tensor rms bound.
         tol["grad_med"] = tol["grad_rms"]
