@@ -1,6 +1,6 @@
 """Diagnostic (GPU): stage-local errors of every instnorm_bwd / convT_s2_dgrad call of the A tape."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import np_oracle as O
 from tests.test_step_gpu import build, dev_inputs, f32_round, perturbed, grads_of
