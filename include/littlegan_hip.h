@@ -140,6 +140,8 @@ int lg_instnorm_leaky_bwd_db(const float* x, const float* stats, const void* g, 
 int lg_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, void* stream);
 int lg_dense_wgrad(const float* x, const float* dy, float* dw, float* db, int B, int K, int N, int accumulate,
                    void* stream);
+/* dx[B][K] = dy[B][N] @ w[K][N]^T (not needed by the step's tapes: the dense inputs are noise / conditions) */
+int lg_dense_dgrad(const float* dy, const float* w, float* dx, int B, int K, int N, void* stream);
 /* p[B][1+c] = sigmoid(x[B][K] @ [wpr | wc] + [bpr | bc]) : column 0 = output_pr, 1.. = output_cond */
 size_t lg_heads_fwd_workspace_bytes(int B, int K, int c);
 int lg_heads_fwd(const float* x, const float* wpr, const float* bpr, const float* wc, const float* bc, float* p,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "lg_instnorm_leaky_bwd_db": (I, [P, P, P, I, P, P, P, P, P, I, P, Z, I, L, I, I, F, I, P]),
     "lg_dense_fwd": (I, [P, P, P, P, I, I, I, P]),
     "lg_dense_wgrad": (I, [P, P, P, P, I, I, I, I, P]),
+    "lg_dense_dgrad": (I, [P, P, P, I, I, I, P]),
     "lg_heads_fwd_workspace_bytes": (Z, [I, I, I]),
     "lg_heads_fwd": (I, [P, P, P, P, P, P, P, Z, I, I, I, P]),
     "lg_heads_dgrad": (I, [P, P, P, P, I, I, I, P]),

@@ -102,6 +102,22 @@ __global__ __launch_bounds__(256) void dense_wgrad_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------- dense dgrad (small K)
+// dx[b][k] = sum_n dy[b][n] w[k][n]: one wave per (b, k) dot product of length N (16-B loads), 4 k's per block.
+// No tape of the training step needs it (the dense inputs are noise / conditions); part of the boundary for completeness.
+__global__ __launch_bounds__(256) void dense_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                          float* __restrict__ dx, int K, int N) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int b = blockIdx.y, k = blockIdx.x * 4 + wid;
+  if (k >= K) return;
+  const float* dr = dy + (long long)b * N;
+  const float* wr = w + (long long)k * N;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int n = lane * 4; n < N; n += 256) acc += *reinterpret_cast<const f32x4*>(dr + n) * *reinterpret_cast<const f32x4*>(wr + n);
+  const float s = lg_wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+  if (lane == 0) dx[(long long)b * K + k] = s;
+}
+
 }  // namespace
 
 extern "C" int lg_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N,
@@ -131,5 +147,13 @@ extern "C" int lg_dense_wgrad(const float* x, const float* dy, float* dw, float*
   dim3 grid(lg_cdiv(N, 256), lg_cdiv(K, KT));
   hipLaunchKernelGGL(dense_wgrad_kernel<KT>, grid, dim3(256), lds, (hipStream_t)stream, x, dy, dw, db, B, K, N, accumulate);
   LG_CHECK_LAUNCH("lg_dense_wgrad");
+  return LG_OK;
+}
+
+extern "C" int lg_dense_dgrad(const float* dy, const float* w, float* dx, int B, int K, int N, void* stream) {
+  LG_CHECK_ARG(dy && w && dx, "lg_dense_dgrad: null pointer");
+  LG_CHECK_ARG(B > 0 && B <= 65535 && K > 0 && N > 0 && N % 4 == 0, "lg_dense_dgrad: bad shape B=%d K=%d N=%d", B, K, N);
+  hipLaunchKernelGGL(dense_dgrad_kernel, dim3(lg_cdiv(K, 4), B), dim3(256), 0, (hipStream_t)stream, dy, w, dx, K, N);
+  LG_CHECK_LAUNCH("lg_dense_dgrad");
   return LG_OK;
 }

@@ -397,6 +397,18 @@ def dense_wgrad(x, dy, dw, db, accumulate=False):
           "lg_dense_wgrad")
 
 
+def dense_dgrad(dy, w, out=None):
+    B, N = dy.shape
+    K = w.shape[0]
+    _chk(dy, name="dy")
+    _chk(w, (K, N), "w")
+    if out is None:
+        out = torch.empty(B, K, dtype=torch.float32, device=dy.device)
+    _chk(out, (B, K), "out")
+    check(_lib.load().lg_dense_dgrad(_p(dy), _p(w), _p(out), B, K, N, _stream()), "lg_dense_dgrad")
+    return out
+
+
 def heads_fwd(x, wpr, bpr, wc, bc, out=None):
     B, K = x.shape
     c = wc.shape[1]

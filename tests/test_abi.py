@@ -45,7 +45,7 @@ def lib():
 def test_header_declares_the_hot_path_entry_points():
     names = set(_protos())
     for n in ("lg_conv2d_s2_fwd", "lg_conv2d_s2_dgrad", "lg_conv2d_s2_wgrad", "lg_convT_s2_fwd", "lg_convT_s2_dgrad",
-              "lg_convT_s2_wgrad", "lg_convT_s1_tanh_fwd", "lg_convT_s1_tanh_bwd", "lg_n3_m16_supported", "lg_convT_s1_tanh_fwd_m16", "lg_convT_s1_tanh_bwd_m16", "lg_dense_fwd", "lg_dense_wgrad",
+              "lg_convT_s2_wgrad", "lg_convT_s1_tanh_fwd", "lg_convT_s1_tanh_bwd", "lg_n3_m16_supported", "lg_convT_s1_tanh_fwd_m16", "lg_convT_s1_tanh_bwd_m16", "lg_dense_fwd", "lg_dense_wgrad", "lg_dense_dgrad",
               "lg_heads_fwd_workspace_bytes", "lg_heads_fwd", "lg_heads_dgrad", "lg_heads_wgrad", "lg_instnorm_leaky_stats", "lg_instnorm_leaky_apply",
               "lg_instnorm_leaky_bwd", "lg_instnorm_bwd_db_workspace_bytes", "lg_instnorm_leaky_bwd_db", "lg_bce_heads_loss_fwd_bwd", "lg_l1_tanh_loss_fwd_bwd", "lg_clip_adam_update", "lg_philox4x32", "lg_randn", "lg_augment_workspace_bytes", "lg_augment"):
         assert n in names

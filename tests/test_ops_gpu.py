@@ -431,3 +431,11 @@ def test_instnorm_bwd_fused_bias_column_sums(ops, shape, g16):
     db2 = torch.empty(C, device="cuda")
     ops.instnorm_bwd(x, st, g, None, None, 0, 1, 0.3, out16=d16, want_f32=False, db=db2)
     assert torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("B,K,N", [(3, 7, 64), (5, 133, 24576), (2, 40, 1024)])
+def test_dense_dgrad(ops, B, K, N):
+    rng = np.random.default_rng(B * 1000 + K)
+    dy, w = r32(rng, B, N), r32(rng, K, N, scale=0.1)
+    dx = ops.dense_dgrad(dev(dy), dev(w))
+    assert rel(dx, dy @ w.T) < 3e-5
