@@ -93,8 +93,11 @@ class EagerTrainer:
         dz = torch.empty(2 * B, 1 + c, dtype=torch.float32, device=self.device)
         ops.bce_heads_loss(p[:B], c1, soft(1.0), 1.0, 2.0, self.losses["disc"], dz[:B], False)
         ops.bce_heads_loss(p[B:], None, soft(0.0), 1.0, 0.0, self.losses["disc"], dz[B:], True)
-        D.backward(ctx_d, dz, need_wgrad=True, need_input_grad=False)
-        self.sync.launch("D", self.store, *self.store.model_range("D"))
+        # a partition step differentiates one weight group only (eager_trainer.py:104-113,145): untrained groups get no
+        # weight-gradient kernels, no all-reduce, and the backward chain stops where nothing below is asked for
+        rng_d = train_weight_range(a, "D", batch_no)
+        D.backward(ctx_d, dz, need_wgrad=True, need_input_grad=False, train_range=rng_d)
+        self.sync.launch("D", self.store, *self.store.model_range("D", *rng_d))
 
         # ---- gen tape (eager_trainer.py:140,149): BCE(.98,fake_pr) + BCE(c2,fake_c) + l1*mean|img2-fake|
         dz_g = torch.empty(B, 1 + c, dtype=torch.float32, device=self.device)
@@ -102,8 +105,9 @@ class EagerTrainer:
         g_img = D.backward(ctx_d, dz_g, need_wgrad=False, need_input_grad=True, rows=slice(B, 2 * B))
         dpre = torch.empty_like(g_img)
         ops.l1_tanh_loss(img2, fake, g_img, dpre, self.losses["gen"], a.l1_lambda, True)
-        G.backward(ctx_g, dpre)
-        self.sync.launch("G", self.store, *self.store.model_range("G"))
+        rng_g = train_weight_range(a, "G", batch_no)
+        G.backward(ctx_g, dpre, train_range=rng_g)
+        self.sync.launch("G", self.store, *self.store.model_range("G", *rng_g))
 
         # ---- adjuster branch (eager_trainer.py:152-164)
         adj_image = None

@@ -152,13 +152,21 @@ class Encoder(_ConvStack):
             ctx["enc"] = saved
         return outs
 
-    def backward(self, ctx, g_last, need_wgrad: bool, need_input_grad: bool, rows: Optional[slice] = None):
+    def backward(self, ctx, g_last, need_wgrad: bool, need_input_grad: bool, rows: Optional[slice] = None,
+                 wgrad_levels=None):
         """g_last: gradient w.r.t. the LAST returned map (the only one any tape of the step uses).
-        rows: restrict to a batch slice of the recorded context (the fake half of a [real;fake] batch)."""
+        rows: restrict to a batch slice of the recorded context (the fake half of a [real;fake] batch).
+        wgrad_levels (with need_wgrad): the levels (1..4) whose 4 weights are differentiated — a partition step
+        (eager_trainer.py:104-113) trains one weight group only, and like the reference's tape.gradient the chain then
+        stops at the lowest level anything is asked of."""
         a = self.args.leaky_alpha
         packs = self.packs()
         g_h = g_last
-        for i in range(4, 0, -1):
+        levels = set(range(1, 5)) if (need_wgrad and wgrad_levels is None) else (set(wgrad_levels or ()) if need_wgrad else set())
+        lowest = 1 if need_input_grad else (min(levels) if levels else 5)
+        any_wgrad = need_wgrad
+        for i in range(4, lowest - 1, -1):
+            need_wgrad = any_wgrad and i in levels
             cb, cs = self.chans[i - 1]
             x, z, st, x16 = ctx["enc"][i - 1]
             if rows is not None:
@@ -167,7 +175,7 @@ class Encoder(_ConvStack):
                 x16 = x16[rows] if x16 is not None else None
             dgm = self._g[f"norm{i}.gamma"] if need_wgrad else None
             dbt = self._g[f"norm{i}.beta"] if need_wgrad else None
-            want_dx = i > 1 or need_input_grad
+            want_dx = i > lowest or (i == 1 and need_input_grad)
             m16 = self.dtype == DT_BF16
             # the fp32 copy of dz is dead when every consumer reads the bf16 mirror: the data-gradient conv (halo kernel,
             # or the tap-product kernel of the 3-channel level 1), the weight-gradient kernel (needs the mirror of x too;
@@ -186,8 +194,8 @@ class Encoder(_ConvStack):
             # the gradient handed to the next (lower) level's norm backward stays bf16 in the bf16 path; the image
             # gradient of level 1 is fp32 (consumed by the loss / tanh backward)
             g_h = (ops.conv2d_s2_dgrad(dz, packs[i - 1], cb, self.dtype, dy16=dz16, out_bf16=(self.dtype == DT_BF16 and i > 1))
-                   if (i > 1 or need_input_grad) else None)
-        return g_h
+                   if want_dx else None)
+        return g_h if need_input_grad else None
 
 
 class Decoder(_ConvStack):
@@ -243,12 +251,17 @@ class Decoder(_ConvStack):
             ctx["dec"] = saved
         return x, x16
 
-    def backward(self, ctx, g_h, need_wgrad: bool):
+    def backward(self, ctx, g_h, need_wgrad: bool, wgrad_levels=None, need_input_grad: bool = True):
         """g_h: fp32 or (bf16 path) bf16.  Returns the gradient w.r.t. the decoder input x (skip tensors receive the same gradient as the
-        level input they were added to; no tape of the step asks for it)."""
+        level input they were added to; no tape of the step asks for it), or None if need_input_grad is False.
+        wgrad_levels / need_input_grad: as Encoder.backward — the chain stops at the lowest level anything is asked of."""
         a = self.args.leaky_alpha
         packs = self.packs()
-        for i in range(4, 0, -1):
+        levels = set(range(1, 5)) if (need_wgrad and wgrad_levels is None) else (set(wgrad_levels or ()) if need_wgrad else set())
+        lowest = 1 if need_input_grad else (min(levels) if levels else 5)
+        any_wgrad = need_wgrad
+        for i in range(4, lowest - 1, -1):
+            need_wgrad = any_wgrad and i in levels
             cb, cs = self.chans[i - 1]
             x, z, st, x16 = ctx["dec"][i - 1]
             dgm = self._g[f"norm{i}.gamma"] if need_wgrad else None
@@ -260,8 +273,10 @@ class Decoder(_ConvStack):
                                   db=self._g[f"conv{i}.bias"] if need_wgrad else None)
             if need_wgrad:
                 ops.convT_s2_wgrad(x, dz, self._g[f"conv{i}.kernel"], False, self.dtype, x16=x16, dy16=dz16)
-            g_h = ops.convT_s2_dgrad(dz, packs[i - 1], cs, self.dtype, dy16=dz16, out_bf16=(self.dtype == DT_BF16 and i > 1))
-        return g_h
+            want_dx = i > lowest or (i == 1 and need_input_grad)
+            g_h = (ops.convT_s2_dgrad(dz, packs[i - 1], cs, self.dtype, dy16=dz16, out_bf16=(self.dtype == DT_BF16 and i > 1))
+                   if want_dx else None)
+        return g_h if need_input_grad else None
 
 
 class _FinalConv(_Module):
@@ -285,13 +300,15 @@ class _FinalConv(_Module):
     def __call__(self, x, out=None, x16=None):
         return ops.convT_s1_tanh_fwd(x, self.pack(), self._w["bias"], self.cb, self.dtype, out=out, x16=x16)
 
-    def backward(self, x, dpre, need_wgrad: bool, x16=None):
-        """Returns dL/dx: fp32, or bf16 in the bf16 path (the decoder's norm backward reads either)."""
+    def backward(self, x, dpre, need_wgrad: bool, x16=None, need_dx: bool = True):
+        """Returns dL/dx: fp32, or bf16 in the bf16 path (the decoder's norm backward reads either); None if not need_dx."""
         B, H, W, _ = dpre.shape
         g16 = self.dtype == DT_BF16
-        dx = torch.empty(B, H, W, self.cs, dtype=torch.bfloat16 if g16 else torch.float32, device=dpre.device)
+        dx = torch.empty(B, H, W, self.cs, dtype=torch.bfloat16 if g16 else torch.float32, device=dpre.device) if need_dx else None
+        if not need_dx and not need_wgrad:
+            return None
         ops.convT_s1_tanh_bwd(x if need_wgrad else None, dpre, self.pack(), self.cs, self.dtype,
-                              dx=None if g16 else dx, dx16=dx if g16 else None,
+                              dx=None if (g16 or not need_dx) else dx, dx16=dx if (g16 and need_dx) else None,
                               dw=self._g["kernel"] if need_wgrad else None,
                               db=self._g["bias"] if need_wgrad else None, x16=x16 if need_wgrad else None)
         return dx
@@ -361,11 +378,19 @@ class Generator(_Module):
             ctx["xdec"], ctx["xdec16"], ctx["img"] = xdec, xdec16, img
         return img
 
-    def backward(self, ctx, dpre):
-        """dpre = dL/d(pre-tanh image).  Writes all 22 weight gradients."""
-        g = self.conv.backward(ctx["xdec"], dpre, need_wgrad=True, x16=ctx.get("xdec16"))
-        g = self.decoder.backward(ctx, g, need_wgrad=True)
-        self._dn.backward(ctx, g)
+    def backward(self, ctx, dpre, train_range=None):
+        """dpre = dL/d(pre-tanh image).  Writes the weight gradients of Generator.weights[lo:hi] (train_range; default all
+        22): 0-3 dense + norm, 4i..4i+3 decoder level i, 20-21 final conv — the partition groups of eager_trainer.py:49."""
+        lo, hi = train_range if train_range is not None else (0, 22)
+        final = lo <= 20 and hi >= 22
+        levels = [i for i in range(1, 5) if lo <= 4 * i and 4 * i + 4 <= hi]
+        dn = lo <= 0 and hi >= 4
+        below_final = dn or bool(levels)
+        g = self.conv.backward(ctx["xdec"], dpre, need_wgrad=final, x16=ctx.get("xdec16"), need_dx=below_final)
+        if below_final:
+            g = self.decoder.backward(ctx, g, need_wgrad=bool(levels), wgrad_levels=levels, need_input_grad=dn)
+            if dn:
+                self._dn.backward(ctx, g)
 
 
 class Discriminator(_Module):
@@ -400,16 +425,22 @@ class Discriminator(_Module):
         p = self.forward_packed(inputs, ctx)
         return p[:, :1], p[:, 1:]
 
-    def backward(self, ctx, dz, need_wgrad: bool, need_input_grad: bool, rows: Optional[slice] = None):
-        """dz [B,1+c] = dL/d(logits).  need_wgrad: the disc tape (all 20 gradients); otherwise only the data
-        path down to the image (gen / adj tapes)."""
+    def backward(self, ctx, dz, need_wgrad: bool, need_input_grad: bool, rows: Optional[slice] = None, train_range=None):
+        """dz [B,1+c] = dL/d(logits).  need_wgrad: the disc tape (gradients of Discriminator.weights[lo:hi], train_range,
+        default all 20: 4(i-1)..4i-1 encoder level i, 16-19 the heads); otherwise only the data path down to the image
+        (gen / adj tapes)."""
+        lo, hi = train_range if train_range is not None else (0, 20)
+        heads = need_wgrad and lo <= 16 and hi >= 20
+        levels = [i for i in range(1, 5) if lo <= 4 * (i - 1) and 4 * i <= hi] if need_wgrad else []
         x = ctx["heads_x"] if rows is None else ctx["heads_x"][rows]
-        if need_wgrad:
+        if heads:
             ops.heads_wgrad(x, dz, self._g["dense_pr.kernel"], self._g["dense_pr.bias"], self._g["dense_cond.kernel"],
                             self._g["dense_cond.bias"])
+        if not levels and not need_input_grad:
+            return None  # a heads-only partition step: nothing flows into the encoder
         dx = ops.heads_dgrad(dz, self._w["dense_pr.kernel"], self._w["dense_cond.kernel"])
         i, f = self.args.init_dim, self.args.conv_filter[0]
-        return self.encoder.backward(ctx, dx.view(-1, i, i, f), need_wgrad, need_input_grad, rows)
+        return self.encoder.backward(ctx, dx.view(-1, i, i, f), bool(levels), need_input_grad, rows, wgrad_levels=levels)
 
 
 class Adjuster(_Module):
