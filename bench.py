@@ -50,26 +50,68 @@ def synthetic_inputs(args, device, rank):
                 noise=torch.randn(B, args.noise_dim, generator=g).to(device), new_image=img())
 
 
-def cpu_baseline(workload):
-    """The oracle's torch-CPU fp32 restatement of the SAME step on a bounded sample (B=8), host cores of this box.
-    Label: CPU restatement, not TensorFlow (TF 1.15 cannot run in this pipeline)."""
+def _cpu_time_step(cfg_kw, Bc, min_steps, budget_s, max_steps=20):
+    """Times the oracle's torch-CPU fp32 restatement of the step on the host cores: (images/sec, steps, s/step)."""
     from oracle import np_oracle as O
     from oracle import torch_oracle as T
-    Bc = 8
-    idim = 16 if workload == "c5" else 8
-    cfg = O.Cfg(batch_size=Bc, cond_dim=40, train_adj=(workload != "c2"), init_dim=idim)
+    cfg = O.Cfg(batch_size=Bc, cond_dim=40, **cfg_kw)
     W = O.init_weights(cfg, 0)
     tr = T.Trainer(cfg, W, dtype=torch.float32)
     inp = {k: torch.tensor(v, dtype=torch.float32) for k, v in O.make_inputs(cfg, Bc, 1234).items()}
-    tr.step(11, inp)  # warm-up (allocations, oneDNN primitives)
+    for w in range(3):  # >= 3 warm-up steps (BASELINE.md par. 3): allocations, oneDNN primitives
+        tr.step(11 + w, inp)
     n, t0 = 0, time.perf_counter()
-    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 20):
-        tr.step(12 + n, inp)
+    while n < min_steps or (time.perf_counter() - t0 < budget_s and n < max_steps):
+        tr.step(14 + n, inp)
         n += 1
     dt = (time.perf_counter() - t0) / n
-    return {"value": round(Bc / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"torch-CPU fp32 restatement (oracle/torch_oracle.py) of the same {workload} step at {idim * 16}x{idim * 16}, "
-                      f"batch {Bc}, {n} timed steps, {dt:.2f} s/step, nproc={os.cpu_count()}"}
+    return Bc / dt, n, dt
+
+
+def cpu_baseline(workload, full=False):
+    """The oracle's torch-CPU fp32 restatement of the SAME step on a bounded sample (B=8), host cores of this box, plus
+    the two CPU-sized configurations SURVEY.md par. 8d names (C1: 64x64, B=16, full step; C2: 128x128, G+D only — at B=16
+    by default, at the full B=64 with --cpu-baseline-full).  >= 3 warm-up + >= 10 timed steps each.
+    Label: CPU restatement, not TensorFlow (TF 1.15 cannot run in this pipeline)."""
+    Bc = 8
+    idim = 16 if workload == "c5" else 8
+    v, n, dt = _cpu_time_step(dict(train_adj=(workload != "c2"), init_dim=idim), Bc, 10, 10.0)
+    out = {"value": round(v, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"torch-CPU fp32 restatement (oracle/torch_oracle.py) of the same {workload} step at {idim * 16}x{idim * 16}, "
+                     f"batch {Bc}, {n} timed steps after 3 warm-up, {dt:.2f} s/step, nproc={os.cpu_count()}"}
+    v1, n1, dt1 = _cpu_time_step(dict(train_adj=True, init_dim=4), 16, 10, 5.0)
+    b2 = 64 if full else 16
+    v2, n2, dt2 = _cpu_time_step(dict(train_adj=False, init_dim=8), b2, 10, 5.0, max_steps=10)
+    out["other_shapes"] = {
+        "C1 (64x64, B=16, cond 40, G+D+Adj)": {"images_per_sec": round(v1, 3), "steps": n1, "s_per_step": round(dt1, 3)},
+        f"C2 (128x128, B={b2}, f32, G+D only)": {"images_per_sec": round(v2, 3), "steps": n2, "s_per_step": round(dt2, 3)}}
+    return out
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N FRESH rank processes (torch.distributed.run, one per GPU)
+    before this process has touched the GPU, relay their output (rank 0 prints the JSON line) and exit with the
+    launcher's code — a failed rank is a failed bench, never a re-exec of a process that holds the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+    proc = subprocess.Popen(cmd, env=env)
+    try:
+        rc = proc.wait()
+    except BaseException:
+        proc.terminate()
+        try:
+            proc.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+        raise
+    raise SystemExit(rc)
 
 
 def main():
@@ -79,18 +121,31 @@ def main():
     ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="time the C2 CPU shape at its full batch 64 (minutes)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo: rehearsal of the N>1 path")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo; RCCL refuses it)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a)  # does not return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if a.share_gpu:
+        if a.backend != "gloo":
+            raise SystemExit("--share-gpu needs --backend gloo (RCCL does not run two ranks on one device)")
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     from littlegan_amd import ops
     from littlegan_amd.eager_trainer import EagerTrainer
@@ -175,7 +230,7 @@ def main():
             "parity": "checked against the in-repo fp64 restatement (tests/); parity to TensorFlow 1.15 is UNPINNED",
         }
         if not a.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0), on a bounded sample
-            out["cpu_baseline"] = cpu_baseline(a.workload)
+            out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_baseline_full)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -47,6 +47,8 @@ int lg_conv2d_s2_fwd(const float* x, const void* pack, const float* bias, float*
 /* same + fused InstanceNormalization moment partials of y (instance.py:114-115): when the chosen kernel supports it,
  * *nparts > 0 and spart holds [B][*nparts][3] doubles {count, mean, M2}; finish with lg_instnorm_stats_finalize.
  * *nparts == 0: not produced, use lg_instnorm_leaky_stats. */
+/* spart size that is always enough for a layer: mode 0 = conv (Hm x Wm = OUTPUT map), 1 = transposed conv (INPUT map) */
+size_t lg_conv_stats_workspace_bytes(int mode, int B, int Hm, int Wm, int N);
 int lg_conv2d_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y, int B, int Hs,
                            int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes, int* nparts, void* stream);
 /* *_m16: the activation operands may additionally be given as bf16 mirrors (x16 / dy16, same layout, may be null);
@@ -179,6 +181,13 @@ size_t lg_augment_workspace_bytes(int B);
 int lg_augment(const float* img, float* out, int B, int H, int W, const unsigned char* flip, float db, float cf, float dh,
                float noise_scale, unsigned long long seed, unsigned long long offset, void* workspace, size_t ws_bytes,
                void* stream);
+size_t lg_augment_drawn_workspace_bytes(int B);
+/* the same with the random draws of :127-130 made on the device (no host round trip on the step's input side):
+ * word w of the Philox window at draw_offset gives u_w = (bits >> 8) / 2^24;  db = (2 u_0 - 1) db_max,
+ * cf = c_lo + u_1 (c_hi - c_lo), dh = (2 u_2 - 1) dh_max, image n is flipped iff u_{3+n} < 1/2 */
+int lg_augment_drawn(const float* img, float* out, int B, int H, int W, float db_max, float c_lo, float c_hi, float dh_max,
+                     float noise_scale, unsigned long long seed, unsigned long long draw_offset,
+                     unsigned long long noise_offset, void* workspace, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,7 @@ SIGNATURES = {
     "lg_conv_pack_bytes": (Z, [I, I, I]),
     "lg_conv_pack": (I, [P, P, I, I, I, P]),
     "lg_conv2d_s2_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "lg_conv_stats_workspace_bytes": (Z, [I, I, I, I, I]),
     "lg_conv2d_s2_fwd_stats": (I, [P, P, P, P, P, I, I, I, I, I, I, P, Z, P, P]),
     "lg_conv2d_s2_dgrad_m16": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "lg_conv2d_s2_wgrad_m16": (I, [P, P, P, P, P, P, Z, I, I, I, I, I, I, I, P]),
@@ -69,6 +70,8 @@ SIGNATURES = {
     "lg_randn": (I, [P, L, F, F, L, L, P]),
     "lg_augment_workspace_bytes": (Z, [I]),
     "lg_augment": (I, [P, P, I, I, I, P, F, F, F, F, L, L, P, Z, P]),
+    "lg_augment_drawn_workspace_bytes": (Z, [I]),
+    "lg_augment_drawn": (I, [P, P, I, I, I, F, F, F, F, F, L, L, L, P, Z, P]),
 }
 
 

@@ -103,7 +103,9 @@ __device__ __forceinline__ void hue_rotate(float& r, float& g, float& b, float d
 __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ img, float* __restrict__ out,
                                                       const float* __restrict__ means, const unsigned char* __restrict__ flip,
                                                       int B, int H, int W, float db, float cf, float dh, float nscale,
-                                                      unsigned long long seed, unsigned long long offset) {
+                                                      unsigned long long seed, unsigned long long offset,
+                                                      const float* __restrict__ dparams) {
+  if (dparams) { db = dparams[0]; cf = dparams[1]; dh = dparams[2]; }  // draws made on the device (draws_kernel)
   const long long npix = (long long)B * H * W, stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
     const int x = (int)(i % W);
@@ -126,6 +128,25 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
     float* o = out + i * 3;
     o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
   }
+}
+
+// The scalar draws of the TF ops (eager_trainer.py:127-130: one brightness delta, one contrast factor, one hue delta per
+// batch; one coin per image for the flip) from the Philox window at `offset`: word w of the window is 24-bit uniform
+// u_w = (bits >> 8) / 2^24;  u_0 -> brightness, u_1 -> contrast, u_2 -> hue, u_{3+n} -> flip of image n.
+// params[0..2] = {db, cf, dh}; flip[n] = u_{3+n} < 0.5.  No host round trip: the step has no sync on its input side.
+__global__ __launch_bounds__(256) void draws_kernel(float* __restrict__ params, unsigned char* __restrict__ flip, int B,
+                                                    float db_max, float c_lo, float c_hi, float dh_max,
+                                                    unsigned long long seed, unsigned long long offset) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;  // word index of the window
+  if (w >= B + 3) return;
+  const unsigned long long c = offset + (unsigned long long)(w >> 2);
+  const u4 r = philox4x32_10(u4{(unsigned)c, (unsigned)(c >> 32), 0u, 0u}, (unsigned)seed, (unsigned)(seed >> 32));
+  const unsigned bits = (w & 3) == 0 ? r.x : (w & 3) == 1 ? r.y : (w & 3) == 2 ? r.z : r.w;
+  const float u = (float)(bits >> 8) * (1.0f / 16777216.0f);
+  if (w == 0) params[0] = (2.0f * u - 1.0f) * db_max;
+  else if (w == 1) params[1] = c_lo + u * (c_hi - c_lo);
+  else if (w == 2) params[2] = (2.0f * u - 1.0f) * dh_max;
+  else flip[w - 3] = u < 0.5f ? 1 : 0;
 }
 
 inline int grid_for(long long n) {
@@ -166,7 +187,36 @@ extern "C" int lg_augment(const float* img, float* out, int B, int H, int W, con
   hipLaunchKernelGGL(chan_mean3_kernel, dim3(B), dim3(256), 0, st, img, means, H * W);
   LG_CHECK_LAUNCH("lg_augment(mean)");
   hipLaunchKernelGGL(augment_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, st, img, out, (const float*)means,
-                     flip, B, H, W, db, cf, dh, noise_scale, seed, offset);
+                     flip, B, H, W, db, cf, dh, noise_scale, seed, offset, (const float*)nullptr);
   LG_CHECK_LAUNCH("lg_augment");
+  return LG_OK;
+}
+
+extern "C" size_t lg_augment_drawn_workspace_bytes(int B) {
+  return ((size_t)B * 3 * sizeof(float) + 15) / 16 * 16 + 16 + ((size_t)B + 15) / 16 * 16;
+}
+
+// lg_augment with the random draws of eager_trainer.py:127-130 made ON THE DEVICE from the Philox window at draw_offset
+// (see draws_kernel): flip per image with probability 1/2, brightness delta U(-db_max, db_max), contrast factor
+// U(c_lo, c_hi), hue delta U(-dh_max, dh_max); the pixel noise uses the window at noise_offset as in lg_augment.
+// The whole input side of the step is then enqueued without a host synchronisation.
+extern "C" int lg_augment_drawn(const float* img, float* out, int B, int H, int W, float db_max, float c_lo, float c_hi,
+                                float dh_max, float noise_scale, unsigned long long seed, unsigned long long draw_offset,
+                                unsigned long long noise_offset, void* workspace, size_t ws_bytes, void* stream) {
+  LG_CHECK_ARG(img && out && img != out && workspace, "lg_augment_drawn: null pointer (or in-place call)");
+  LG_CHECK_ARG(B > 0 && H > 0 && W > 0, "lg_augment_drawn: bad shape B=%d H=%d W=%d", B, H, W);
+  LG_CHECK_ARG(ws_bytes >= lg_augment_drawn_workspace_bytes(B), "lg_augment_drawn: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* means = (float*)workspace;
+  float* params = (float*)((char*)workspace + ((size_t)B * 3 * sizeof(float) + 15) / 16 * 16);
+  unsigned char* flip = (unsigned char*)(params + 4);
+  hipLaunchKernelGGL(draws_kernel, dim3((B + 3 + 255) / 256), dim3(256), 0, st, params, flip, B, db_max, c_lo, c_hi, dh_max,
+                     seed, draw_offset);
+  LG_CHECK_LAUNCH("lg_augment_drawn(draws)");
+  hipLaunchKernelGGL(chan_mean3_kernel, dim3(B), dim3(256), 0, st, img, means, H * W);
+  LG_CHECK_LAUNCH("lg_augment_drawn(mean)");
+  hipLaunchKernelGGL(augment_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, st, img, out, (const float*)means,
+                     (const unsigned char*)flip, B, H, W, 0.f, 1.f, 1.f, noise_scale, seed, noise_offset, (const float*)params);
+  LG_CHECK_LAUNCH("lg_augment_drawn");
   return LG_OK;
 }

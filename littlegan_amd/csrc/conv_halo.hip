@@ -680,6 +680,16 @@ extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const voi
   return LG_OK;
 }
 
+// Bytes of the moment-partials buffer (`spart`) a fused-statistics conv of this shape may need: B samples x the partial
+// records of the finest tiling (one per 128-pixel tile, 32-column slice and — UP — parity class) x {count, mean, M2}
+// doubles.  mode 0 = conv ("down": Hm x Wm is the OUTPUT map), 1 = transposed conv ("up": Hm x Wm is the INPUT map).
+extern "C" size_t lg_conv_stats_workspace_bytes(int mode, int B, int Hm, int Wm, int N) {
+  if (B <= 0 || Hm <= 0 || Wm <= 0 || N <= 0) return 0;
+  const long long tiles = ((long long)Hm * Wm + 127) / 128;
+  const long long worst = (mode == MODE_UP ? 4 : 1) * tiles * (lg_npad(N) / 32);
+  return (size_t)B * (size_t)worst * 3 * sizeof(double) + 256;
+}
+
 // 1 if the halo kernel covers this shape (then the bf16 mirror alone is enough as its source), else 0
 extern "C" int lg_conv_halo_supported(int mode, int dtype, int B, int Hm, int Wm, int Cs, int N) {
   static const int dummy = 0;

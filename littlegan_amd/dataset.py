@@ -39,7 +39,12 @@ class CelebA:
             self._image_list = files
             self._attributes_list = self._get_attr_list(args.attr_path, args.attr)
             self.n = len(files)
-        self.batches = self.n // args.batch_size
+        # data parallel: the (seeded, rank-independent) batch order is dealt round-robin to the ranks, every rank takes
+        # the same number of batches per epoch (the gradient all-reduce needs matching step counts)
+        d = torch.distributed
+        self.rank, self.world = (d.get_rank(), d.get_world_size()) if (d.is_available() and d.is_initialized()) else (0, 1)
+        self.total_batches = self.n // args.batch_size
+        self.batches = self.total_batches // self.world
         self._gen = torch.Generator().manual_seed(int(getattr(args, "seed", 0)) + 17)
 
     @staticmethod
@@ -54,7 +59,8 @@ class CelebA:
 
     def _order(self):
         # dataset.py:21-22: batch THEN shuffle with a `prefetch`-sized buffer; a full permutation of batches here
-        return torch.randperm(self.batches, generator=self._gen).tolist()
+        order = torch.randperm(self.total_batches, generator=self._gen).tolist()
+        return order[self.rank::self.world][:self.batches]
 
     def _batch(self, b):
         a = self.args

@@ -23,6 +23,19 @@ from .utils import save_image, soft
 ADAM_EPS = 1e-8
 
 
+def _dist_rank_world():
+    d = torch.distributed
+    if d.is_available() and d.is_initialized():
+        return d.get_rank(), d.get_world_size()
+    return 0, 1
+
+
+def _barrier():
+    d = torch.distributed
+    if d.is_available() and d.is_initialized() and d.get_world_size() > 1:
+        d.barrier()
+
+
 def train_weight_range(args, model: str, batch_no: int):
     """eager_trainer.py:104-113 + part_groups :48-52 as (lo, hi) weight-index ranges."""
     groups = {"G": [(0, 4), (4, 8), (8, 22)], "D": [(0, 12), (12, 16), (16, 20)], "A": [(0, 4)]}[model]
@@ -53,6 +66,8 @@ class EagerTrainer:
         self.losses = {k: torch.zeros(1, dtype=torch.float32, device=self.device) for k in ("gen", "disc", "adj")}
         self.sync = GradSync(self.device)
         self.global_epoch = 1
+        self._input_step = 0  # counter window of the device-side step inputs (draw_step_inputs); part of the checkpoint
+        self.rank, self.world = _dist_rank_world()
         self._init_dir()
         # eager_trainer.py:36-43: restore the newest checkpoint (weights, the three optimizers' slots and beta powers)
         # and the epoch from status.json when args.restore is set
@@ -166,20 +181,16 @@ class EagerTrainer:
         draws are counter-based (Philox4x32-10 keyed by args.seed and the rank; one 2^40-block counter window per step),
         so a step's inputs can be regenerated from (seed, rank, step) alone."""
         a = self.args
-        step = self._input_step = getattr(self, "_input_step", 0) + 1
-        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
-        seed = (int(getattr(a, "seed", 0)) << 20) ^ rank
+        self._input_step += 1
+        step = self._input_step
+        seed = (int(getattr(a, "seed", 0)) << 20) ^ self.rank
         base = step << 40
         noise = ops.randn((a.batch_size, a.noise_dim), seed, base, device=self.device)
-        # the scalar draws of the TF ops (one per batch) and the per-image flips: a few bytes from the block window at 2^39
-        nb = (a.batch_size + 3 + 3) // 4 + 1
-        bits = ops.philox4x32(nb, seed, base + (1 << 39), device=self.device).cpu().numpy().view("uint32")
-        u = (bits >> 8).astype("float64") / 16777216.0
-        db = (2.0 * u[0] - 1.0) * 0.02                    # random_brightness(0.02)
-        cf = 0.75 + u[1] * (1.003 - 0.75)                 # random_contrast(0.75, 1.003)
-        dh = (2.0 * u[2] - 1.0) * 0.03                    # random_hue(0.03)
-        flip = torch.tensor((u[3:3 + a.batch_size] < 0.5).astype("uint8"), device=self.device)
-        new_image = ops.augment(real_image_1.contiguous(), flip, db, cf, dh, 0.1 * 0.2, seed, base + (1 << 38))
+        # the scalar draws of the TF ops (one per batch) and the per-image flips come from the block window at 2^39 and are
+        # made ON THE DEVICE (lg_augment_drawn): random_brightness(0.02), random_contrast(0.75, 1.003), random_hue(0.03),
+        # random_flip_left_right, + 0.1 * N(0, 0.2) from the window at 2^38 — no host synchronisation in the step
+        new_image = ops.augment_drawn(real_image_1.contiguous(), 0.02, 0.75, 1.003, 0.03, 0.1 * 0.2, seed,
+                                      base + (1 << 39), base + (1 << 38))
         return noise, new_image
 
     # ------------------------------------------------------------------ eager_trainer.py:180-229
@@ -195,7 +206,9 @@ class EagerTrainer:
 
     def train(self):
         a = self.args
-        io = not getattr(a, "no_io", False) and getattr(a, "result_dir", None)
+        # data parallel (one process per GPU): every file of the run is written by rank 0 alone — two ranks writing the
+        # same checkpoint / image / JSON paths race (and a rank that dies there leaves the others in an all-reduce)
+        io = not getattr(a, "no_io", False) and getattr(a, "result_dir", None) and self.rank == 0
         if io:
             import signal
             signal.signal(signal.SIGINT, self._interrupted)
@@ -212,14 +225,15 @@ class EagerTrainer:
                 elif not result[0]:
                     continue
                 seen += a.batch_size * 2
-                if b % a.freq_gen == 0:
-                    save_image(result[1], os.path.join(a.result_dir, "train", "gen", "%d-%d.jpg" % (e, b)))
-                    if result[2] is not None:
-                        save_image(result[2], os.path.join(a.result_dir, "train", "adj", "%d-%d.jpg" % (e, b)))
+                if b % a.freq_gen == 0 and self.rank == 0:
+                    if io:
+                        save_image(result[1], os.path.join(a.result_dir, "train", "gen", "%d-%d.jpg" % (e, b)))
+                        if result[2] is not None:
+                            save_image(result[2], os.path.join(a.result_dir, "train", "adj", "%d-%d.jpg" % (e, b)))
                     lg, ld = float(result[3]), float(result[4])
                     la = float(result[5]) if result[5] is not None else float("nan")
                     print(f"  [{seen}] LossG {lg:.4f} LossD {ld:.4f} LossA {la:.4f}")
-                if b % a.freq_test == 0:
+                if b % a.freq_test == 0 and io and self.test_cond is not None:
                     self.predict(self.test_noise, self.test_cond, self.test_image,
                                  os.path.join(a.result_dir, "test", "gen", "%d-%d.jpg" % (e, b)),
                                  os.path.join(a.result_dir, "test", "disc", "%d-%d.json" % (e, b)),
@@ -228,6 +242,7 @@ class EagerTrainer:
             print("Time usage:", time.time() - start_time, "s")
             if io:  # eager_trainer.py:229
                 self.save_checkpoint(str(e))
+            _barrier()  # the other ranks do not run ahead into the next epoch while rank 0 writes
 
     # ------------------------------------------------------------------ eager_trainer.py:265-298
     def predict(self, noise, cond, image, gen_image_save_path=None, json_save_path=None, adj_image_save_path=None):
@@ -269,12 +284,31 @@ class EagerTrainer:
             os.makedirs(os.path.join(rd, item), exist_ok=True)
 
     def _init_test_data(self):
+        """eager_trainer.py:65-83: the FIXED evaluation batch {n: noise, c: cond, i: image} of `predict`.  Loaded from
+        <test_data_dir>/test_data_<env>.npz when that file exists and args.reuse is set; otherwise drawn once (first
+        batch of a fresh iterator + N(0,1) noise) and written there, so every later run evaluates the same batch."""
+        import numpy as np
         self.test_noise = self.test_cond = self.test_image = None
+        a = self.args
+        tdir = getattr(a, "test_data_dir", None)
+        npz = os.path.join(tdir, "test_data_" + str(getattr(a, "env", "default")) + ".npz") if tdir else None
+        if npz and os.path.isfile(npz) and getattr(a, "reuse", False):
+            data = np.load(npz)
+            to = lambda v: torch.tensor(np.asarray(v, np.float32), device=self.device)
+            self.test_noise, self.test_cond, self.test_image = to(data["n"]), to(data["c"]), to(data["i"])
+            return
         if self.dataset is None:
             return
+        print("No reuse test data, generating...")
         it = self.dataset.get_new_iterator()
         self.test_image, self.test_cond = it.get_next()
-        self.test_noise = torch.randn(self.test_cond.shape[0], self.args.noise_dim, device=self.device)
+        # tf.random.normal([B, noise_dim]) (:82) from the counter-based generator: window 0 is never used by a step
+        seed = (int(getattr(a, "seed", 0)) << 20) ^ 0xFFFFF
+        self.test_noise = ops.randn((self.test_cond.shape[0], a.noise_dim), seed, 0, device=self.device)
+        if npz and self.rank == 0 and not getattr(a, "no_io", False):
+            os.makedirs(tdir, exist_ok=True)
+            np.savez_compressed(npz, n=self.test_noise.cpu().numpy(), c=self.test_cond.cpu().numpy(),
+                                i=self.test_image.cpu().numpy())
 
     # ---- checkpoints (own format: the TF checkpoint format is out of scope, the CONTENT is the reference's:
     # tf.train.Checkpoint(discriminator, generator, adjuster, three optimizers) eager_trainer.py:31-35)
@@ -284,10 +318,13 @@ class EagerTrainer:
                 "names": {m: st.names(m) for m in "GDA"},
                 "flat": st.flat.detach().cpu(), "adam_m": st.m.detach().cpu(), "adam_v": st.v.detach().cpu(),
                 "beta_powers": {m: t.detach().cpu() for m, t in self.opt_state.items()},
-                "epoch": self.global_epoch}
+                "epoch": self.global_epoch, "input_step": int(self._input_step)}
 
     def save_checkpoint(self, tag: str) -> str:
+        """Rank 0 writes (weights are identical on every rank after the all-reduced step); other ranks return the path."""
         d = os.path.join(self.args.result_dir, "checkpoint")
+        if self.rank != 0:
+            return os.path.join(d, f"ckpt-{tag}.pt")
         os.makedirs(d, exist_ok=True)
         path = os.path.join(d, f"ckpt-{tag}.pt")
         tmp = path + ".tmp"
@@ -321,6 +358,7 @@ class EagerTrainer:
         st.v.copy_(ck["adam_v"])
         for m, t in ck["beta_powers"].items():
             self.opt_state[m].copy_(t)
+        self._input_step = int(ck.get("input_step", 0))  # a resumed run continues the Philox input stream
         st.bump()
 
     def export_model_checkpoint(self):

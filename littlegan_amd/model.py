@@ -393,6 +393,29 @@ class Generator(_Module):
                 self._dn.backward(ctx, g)
 
 
+class _DenseHead:
+    """`Dense(n, activation=sigmoid)` attribute of the reference's Discriminator (model.py:62-63) as a view of the
+    weights the fused heads kernels use: .kernel, .bias, .weights (keras order) and a call y = sigmoid(x W + b)."""
+
+    def __init__(self, owner: "_Module", name: str):
+        self._o, self._n = owner, name
+
+    @property
+    def kernel(self):
+        return self._o._w[self._n + ".kernel"]
+
+    @property
+    def bias(self):
+        return self._o._w[self._n + ".bias"]
+
+    @property
+    def weights(self):
+        return [self.kernel, self.bias]
+
+    def __call__(self, x):
+        return torch.sigmoid(ops.dense_fwd(x.contiguous(), self.kernel, self.bias))
+
+
 class Discriminator(_Module):
     """model.py:54-73.  Returns (output_pr [B,1], output_cond [B,cond_dim]) as views of one [B,1+c] buffer."""
 
@@ -404,6 +427,8 @@ class Discriminator(_Module):
         self._add("dense_pr.bias", (1,), "zeros")
         self._add("dense_cond.kernel", (k, args.cond_dim), "kernel")
         self._add("dense_cond.bias", (args.cond_dim,), "zeros")
+        self.dense_pr = _DenseHead(self, "dense_pr")      # model.py:62
+        self.dense_cond = _DenseHead(self, "dense_cond")  # model.py:63
 
     def parts(self):
         return [("enc.", self.encoder), ("disc.", self)]

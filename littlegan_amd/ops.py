@@ -486,12 +486,12 @@ def adam_advance(state, b1, b2):
 
 
 # ------------------------------------------------------------------ conv forward with fused InstanceNorm moments
-def _fwd_stats(fn_name, x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, tag, flops):
+def _fwd_stats(fn_name, x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, tag, flops, up):
     """Runs the conv; if its kernel produced per-block moment partials, finishes them into the stats record.
     Returns stats [B, NSTAT] or None (caller then runs instnorm_stats on the output)."""
     import ctypes
     lib = _lib.load()
-    ws = workspace(B * 1024 * 24, out.device, "statpart")  # >= B * nparts * 3 doubles for every layer shape (nparts <= 1024)
+    ws = workspace(int(lib.lg_conv_stats_workspace_bytes(int(up), B, Hs, Ws, cb if up else cs)), out.device, "statpart")
     nparts = ctypes.c_int(0)
     e0 = _pb()
     if x16 is not None:
@@ -517,7 +517,7 @@ def conv2d_s2_fwd_stats(x, pack, bias, cs, dtype, gamma, beta, x16=None):
         raise ValueError("conv2d_s2_fwd_stats: H and W must be even")
     out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.float32, device=bias.device)
     st = _fwd_stats("lg_conv2d_s2_fwd_stats", x, x16, pack, bias, out, B, H // 2, W // 2, cb, cs, dtype, gamma, beta,
-                    "conv_igemm_patch" if cb == 3 else "conv_igemm_down", 50.0 * B * (H // 2) * (W // 2) * cb * cs)
+                    "conv_igemm_patch" if cb == 3 else "conv_igemm_down", 50.0 * B * (H // 2) * (W // 2) * cb * cs, up=False)
     return out, st
 
 
@@ -528,7 +528,7 @@ def convT_s2_fwd_stats(x, pack, bias, cb, dtype, gamma, beta, x16=None):
     _chk(bias, (cb,), "bias")
     out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.float32, device=bias.device)
     st = _fwd_stats("lg_convT_s2_fwd_stats", x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, "conv_igemm_up",
-                    50.0 * B * Hs * Ws * cb * cs)
+                    50.0 * B * Hs * Ws * cb * cs, up=True)
     return out, st
 
 
@@ -567,4 +567,22 @@ def augment(img, flip, db, cf, dh, noise_scale, seed, offset, out=None):
     ws = workspace(int(lib.lg_augment_workspace_bytes(B)), img.device, "small")
     check(lib.lg_augment(_p(img), _p(out), B, H, W, _p(flip), float(db), float(cf), float(dh), float(noise_scale),
                          _i64(seed), _i64(offset), _p(ws), ws.numel(), _stream()), "lg_augment")
+    return out
+
+
+def augment_drawn(img, db_max, c_lo, c_hi, dh_max, noise_scale, seed, draw_offset, noise_offset, out=None):
+    """lg_augment_drawn: flip / brightness / contrast / hue draws made on the device from the Philox window at
+    draw_offset (no host synchronisation); see include/littlegan_hip.h."""
+    B, H, W, c = img.shape
+    _chk(img, name="img")
+    if c != 3:
+        raise ValueError("augment_drawn: 3-channel images only")
+    if out is None:
+        out = torch.empty_like(img)
+    _chk(out, img.shape, "out")
+    lib = _lib.load()
+    ws = workspace(int(lib.lg_augment_drawn_workspace_bytes(B)), img.device, "small")
+    check(lib.lg_augment_drawn(_p(img), _p(out), B, H, W, float(db_max), float(c_lo), float(c_hi), float(dh_max),
+                               float(noise_scale), _i64(seed), _i64(draw_offset), _i64(noise_offset), _p(ws), ws.numel(),
+                               _stream()), "lg_augment_drawn")
     return out

@@ -9,7 +9,9 @@ import torch
 
 from littlegan_amd.config import Arg
 
-args = Arg(config_dir=os.path.dirname(os.path.abspath(__file__)))
+# configuration files are looked up next to this script (the reference reads them from the working directory);
+# LITTLEGAN_CONFIG_DIR points somewhere else (tests)
+args = Arg(config_dir=os.environ.get("LITTLEGAN_CONFIG_DIR", os.path.dirname(os.path.abspath(__file__))))
 
 from littlegan_amd.dataset import CelebA
 from littlegan_amd.eager_trainer import EagerTrainer
@@ -18,9 +20,14 @@ from littlegan_amd.utils import save_image
 
 if "LOCAL_RANK" in os.environ:  # one process per GPU (torchrun); the reference's -g only set CUDA_VISIBLE_DEVICES
     import torch.distributed as dist
-    torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
-    args.device = f"cuda:{os.environ['LOCAL_RANK']}"
-    dist.init_process_group("nccl", device_id=torch.device(args.device))
+    if os.environ.get("LITTLEGAN_DP_BACKEND", "nccl") == "gloo":  # rehearsal: ranks share cuda:0, gloo moves the tensors
+        args.device = "cuda:0"
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+        args.device = f"cuda:{os.environ['LOCAL_RANK']}"
+        dist.init_process_group("nccl", device_id=torch.device(args.device))
 print("Application Params: ", args)
 print("Running Mode:", args.mode)
 print(" - Initializing Networks...")

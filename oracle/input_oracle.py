@@ -69,3 +69,11 @@ def augment(img, flip, db, cf, dh):
     m = x.mean(axis=(1, 2), keepdims=True)
     x = (x - m) * cf + m
     return hue_rotate(x, dh) if dh != 0 else x
+
+
+def step_draws(B, seed, offset, db_max=0.02, c_lo=0.75, c_hi=1.003, dh_max=0.03):
+    """The scalar draws of eager_trainer.py:127-130 as lg_augment_drawn makes them: word w of the Philox window at
+    `offset` -> u_w = (bits >> 8) / 2^24; returns (db, cf, dh, flip[B])."""
+    nb = (B + 3 + 3) // 4
+    u = (philox_blocks(nb, seed, offset).reshape(-1) >> np.uint32(8)).astype(np.float64) / 16777216.0
+    return (2.0 * u[0] - 1.0) * db_max, c_lo + u[1] * (c_hi - c_lo), (2.0 * u[2] - 1.0) * dh_max, u[3:3 + B] < 0.5

@@ -35,10 +35,29 @@ def _inputs(cfg, world, b):
     return f32_round(O.make_inputs(cfg, cfg.batch_size * world, seed=300 + b))
 
 
-def _worker(rank, world, port, mfma, outdir):
+def _join_all(procs, timeout):
+    """Join every rank; on a timeout or a failure terminate exactly the processes this test started."""
+    try:
+        for p in procs:
+            p.join(timeout=timeout)
+            assert p.exitcode == 0, f"rank process exit code {p.exitcode}"
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=20)
+                if p.is_alive():
+                    p.kill()
+
+
+def _worker(rank, world, port, mfma, outdir, backend="gloo"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":  # RCCL over xGMI: one rank per GPU
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         cfg = O.Cfg(**CFG)
         tr = build(cfg, perturbed(cfg, 21), mfma)
@@ -55,17 +74,22 @@ def _worker(rank, world, port, mfma, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mfma", ["f32", "bf16"])
-def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path, mfma):
+def _dp_params():
+    out = [pytest.param("f32", "gloo"), pytest.param("bf16", "gloo")]
+    two = torch.cuda.is_available() and torch.cuda.device_count() >= 2
+    out.append(pytest.param("bf16", "nccl", marks=pytest.mark.skipif(not two, reason="RCCL path needs >= 2 GPUs (one rank per device)")))
+    return out
+
+
+@pytest.mark.parametrize("mfma,backend", _dp_params())
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path, mfma, backend):
     world = 2
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, mfma, str(tmp_path))) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mfma, str(tmp_path), backend)) for r in range(world)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(timeout=600)
-        assert p.exitcode == 0
+    _join_all(procs, 600)
     flat = [np.load(tmp_path / f"flat_{r}.npy") for r in range(world)]
     grad = [np.load(tmp_path / f"grad_{r}.npy") for r in range(world)]
     # every rank ends with identical weights and identical (all-reduced) gradient buffers
@@ -92,3 +116,59 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path, mfma):
     # weights after two Adam steps (lr 5e-5): Adam normalises the gradient, so parameters whose true gradient is zero
     # (conv biases in front of an InstanceNormalization) move by +-lr on rounding noise alone -> compare the mean
     assert np.abs(flat[0] - w1).mean() < 0.05 * cfg.lr * len(STEPS)
+
+
+def _train_worker(rank, world, port, outdir):
+    """train() with file I/O enabled under data parallelism (the advisor's rank-safety case)."""
+    import torch.distributed as dist
+    from types import SimpleNamespace
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from littlegan_amd.dataset import CelebA
+        from littlegan_amd.eager_trainer import EagerTrainer
+        from littlegan_amd.model import Adjuster, Decoder, Discriminator, Encoder, Generator
+        a = SimpleNamespace(batch_size=2, image_channel=3, noise_dim=5, init_dim=2, conv_filter=[32, 32, 32, 32, 32],
+                            kernel_size=5, leaky_alpha=0.3, dropout_rate=0.5, l1_lambda=0.02, lr=5e-5, beta_1=0.5, beta_2=0.9,
+                            use_gp=False, use_clip=True, clip_range=0.5, use_partition=True, partition_interval=4,
+                            train_adj=True, attr=[1, 2, 3], cond_dim=3, mfma_dtype="f32", device="cuda", seed=3,
+                            synthetic=True, synthetic_images=2 * 2 * 2 * 12, image_dim=32, image_path=None, image_ext="jpg",
+                            attr_path=None, env="dp", reuse=False, restore=False, no_io=False, exp_name="dp", epoch=2,
+                            freq_gen=4, freq_test=6, test_data_dir=os.path.join(outdir, "td"),
+                            result_dir=os.path.join(outdir, "res"))
+        dec, enc = Decoder(a), Encoder(a)
+        g = Generator(a, dec)
+        d = Discriminator(a, enc)
+        ds = CelebA(a)
+        assert ds.batches == 48 // world and ds.world == world
+        order = ds.get_new_iterator().order
+        np.save(os.path.join(outdir, f"order_{rank}.npy"), np.asarray(order))
+        tr = EagerTrainer(a, g, d, Adjuster(a, d, g), ds)
+        dist.broadcast(tr.store.flat, src=0)
+        tr.store.bump()
+        tr.train()
+        torch.cuda.synchronize()
+        np.save(os.path.join(outdir, f"tflat_{rank}.npy"), tr.store.flat.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_loop_with_file_io_is_rank_safe(tmp_path):
+    """Two ranks run EagerTrainer.train() on one result directory: rank 0 alone writes checkpoints / images / JSON, the
+    ranks read disjoint batches, finish both epochs and hold identical weights."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    _join_all(procs, 600)
+    f0, f1 = np.load(tmp_path / "tflat_0.npy"), np.load(tmp_path / "tflat_1.npy")
+    assert np.array_equal(f0, f1)
+    o0, o1 = np.load(tmp_path / "order_0.npy"), np.load(tmp_path / "order_1.npy")
+    assert len(o0) == len(o1) == 24 and not set(o0.tolist()) & set(o1.tolist())   # disjoint shards, equal step counts
+    ck = tmp_path / "res" / "checkpoint"
+    assert (ck / "ckpt-1.pt").is_file() and (ck / "ckpt-2.pt").is_file() and not list(ck.glob("*.tmp"))
+    assert (tmp_path / "res" / "train" / "gen" / "2-4.jpg").is_file() and (tmp_path / "res" / "test" / "disc" / "1-6.json").is_file()
+    state = torch.load(ck / "ckpt-2.pt", map_location="cpu", weights_only=True)
+    assert state["input_step"] == 24   # 12 steps per epoch per rank (24 batches, 2 per step), two epochs: the Philox input stream position is saved

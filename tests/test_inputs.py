@@ -76,6 +76,29 @@ def test_device_augmentation_matches_the_oracle(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 6, 256])
+def test_device_side_draws_match_the_oracle(B):
+    """lg_augment_drawn: flip / brightness / contrast / hue drawn on the device from the Philox window (no host round
+    trip) == the oracle's transform fed with the oracle's reading of the same window."""
+    from littlegan_amd import ops
+    H = W = 16
+    rng = np.random.default_rng(B)
+    img = rng.uniform(-1, 1, (B, H, W, 3)).astype(np.float32)
+    seed, doff, noff = (5 << 20) ^ 1, (9 << 40) + (1 << 39), (9 << 40) + (1 << 38)
+    db, cf, dh, flip = I.step_draws(B, seed, doff)
+    assert abs(db) <= 0.02 and 0.75 <= cf <= 1.003 and abs(dh) <= 0.03
+    x = torch.tensor(img, device="cuda")
+    out = ops.augment_drawn(x, 0.02, 0.75, 1.003, 0.03, 0.0, seed, doff, noff).cpu().numpy()
+    exp = I.augment(img.astype(np.float64), flip, db, cf, dh)
+    assert np.abs(out - exp).max() < 5e-6
+    outn = ops.augment_drawn(x, 0.02, 0.75, 1.003, 0.03, 0.02, seed, doff, noff).cpu().numpy()
+    nz = I.normals(B * H * W, seed, noff)[:, :3].reshape(B, H, W, 3)
+    assert np.abs(outn - (exp + 0.02 * nz)).max() < 8e-6
+    if B == 256:
+        assert 90 < int(flip.sum()) < 166   # a fair coin per image
+
+
+@pytest.mark.gpu
 def test_trainer_draws_reproducible_step_inputs():
     from test_step_gpu import build, perturbed
     from oracle import np_oracle as O
