@@ -71,7 +71,8 @@ def test_fixed_evaluation_batch_is_created_then_reused(tmp_path):
     tr = _trainer(_small_args(tmp_path))
     npz = tmp_path / "td" / "test_data_t.npz"
     assert npz.is_file()
-    data = np.load(npz)
+    with np.load(npz) as f:
+        data = {k: f[k] for k in ("n", "c", "i")}   # read everything before the file is rewritten below
     assert data["n"].shape == (4, 5) and data["c"].shape == (4, 3) and data["i"].shape == (4, 32, 32, 3)
     assert np.array_equal(data["n"], tr.test_noise.cpu().numpy())
     # poison the file's noise: a reuse run must take the FILE's content, a non-reuse run regenerates the batch
