@@ -49,8 +49,14 @@ int lg_conv2d_s2_fwd(const float* x, const void* pack, const float* bias, float*
  * *nparts == 0: not produced, use lg_instnorm_leaky_stats. */
 /* spart size that is always enough for a layer: mode 0 = conv (Hm x Wm = OUTPUT map), 1 = transposed conv (INPUT map) */
 size_t lg_conv_stats_workspace_bytes(int mode, int B, int Hm, int Wm, int N);
-int lg_conv2d_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y, int B, int Hs,
-                           int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes, int* nparts, void* stream);
+/* 1 if the *_fwd_stats call of this shape (up: 0 = lg_conv2d_s2_fwd_stats, 1 = lg_convT_s2_fwd_stats) will return fused
+ * moment partials; Hs x Ws = the small map of the layer */
+int lg_conv_fwd_stats_fused(int up, int dtype, int B, int Hs, int Ws, int cb, int cs);
+/* y16 (may be null; bf16 dtype only): write the result z as bf16 there INSTEAD of fp32 to y (y may then be null) - the
+ * bf16 activation path keeps the raw conv outputs in HBM as bf16; the moments come from the fp32 accumulators. */
+int lg_conv2d_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y, void* y16, int B,
+                           int Hs, int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes, int* nparts,
+                           void* stream);
 /* *_m16: the activation operands may additionally be given as bf16 mirrors (x16 / dy16, same layout, may be null);
  * the bf16 MFMA kernels then read those instead of re-reading and re-rounding the fp32 tensors (bit-identical result) */
 /* dx16 (may be null): write the data gradient as bf16 there INSTEAD of fp32 to dx (dx may then be null) */
@@ -69,8 +75,9 @@ int lg_conv2d_s2_wgrad(const float* x, const float* dy, float* dw, void* workspa
 /* y[B,2Hs,2Ws,cb] = convT(x[B,Hs,Ws,cs]) + bias   (4-phase sub-pixel implicit GEMM) */
 int lg_convT_s2_fwd(const float* x, const void* pack, const float* bias, float* y, int B, int Hs, int Ws, int cb,
                     int cs, int dtype, void* stream);
-int lg_convT_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y, int B, int Hs,
-                          int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes, int* nparts, void* stream);
+int lg_convT_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y, void* y16, int B,
+                          int Hs, int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes, int* nparts,
+                          void* stream);
 int lg_convT_s2_dgrad_m16(const float* dy, const void* dy16, const void* pack, float* dx, void* dx16, int B, int Hs, int Ws,
                           int cb, int cs, int dtype, void* stream);
 int lg_convT_s2_wgrad_m16(const float* x, const void* x16, const float* dy, const void* dy16, float* dw, void* workspace,
@@ -119,6 +126,9 @@ size_t lg_instnorm_workspace_bytes(int B, long long L);
 int lg_instnorm_stats_stride(void);
 int lg_instnorm_leaky_stats(const float* x, float* stats, const float* gamma, const float* beta, void* workspace,
                             size_t ws_bytes, int B, long long L, int pre_leaky, float alpha, void* stream);
+/* same; x16_out (may be null) additionally receives bf16(x) (bf16 activation path, layers without fused moments) */
+int lg_instnorm_leaky_stats_z16(const float* x, float* stats, const float* gamma, const float* beta, void* workspace,
+                                size_t ws_bytes, int B, long long L, int pre_leaky, float alpha, void* x16_out, void* stream);
 int lg_instnorm_stats_finalize(const void* partials, int nparts, float* stats, const float* gamma, const float* beta,
                                int B, void* stream);
 /* y = [post_leaky](a*([pre_leaky](x) - mu) + beta) [+ skip] ; y16 (may be null): bf16 mirror of y, the MFMA operand
@@ -137,6 +147,13 @@ size_t lg_instnorm_bwd_db_workspace_bytes(int B, long long L, int C);
 int lg_instnorm_leaky_bwd_db(const float* x, const float* stats, const void* g, int g_is_bf16, float* dx, void* dx16,
                              float* dgamma, float* dbeta, float* db, int C, void* workspace, size_t ws_bytes, int B,
                              long long L, int pre_leaky, int post_leaky, float alpha, int accumulate, void* stream);
+/* bf16 activation path: the same two ops with the conv output z given as bf16 (z16); skip (may be null) is fp32, or bf16
+ * when skip_is_bf16.  L % 8 == 0.  Workspace of the backward: lg_instnorm_bwd_db_workspace_bytes. */
+int lg_instnorm_leaky_apply_z16(const void* z16, const float* stats, const void* skip, int skip_is_bf16, float* y, void* y16,
+                                int B, long long L, int pre_leaky, int post_leaky, float alpha, void* stream);
+int lg_instnorm_leaky_bwd_z16(const void* z16, const float* stats, const void* g, int g_is_bf16, float* dx, void* dx16,
+                              float* dgamma, float* dbeta, float* db, int C, void* workspace, size_t ws_bytes, int B,
+                              long long L, int pre_leaky, int post_leaky, float alpha, int accumulate, void* stream);
 
 /* ---- tf.compat.v1.layers.Dense  model.py:62-63 (heads, sigmoid), :83, :120 ----------------------- */
 int lg_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, void* stream);

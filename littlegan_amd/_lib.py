@@ -23,13 +23,14 @@ SIGNATURES = {
     "lg_conv_pack": (I, [P, P, I, I, I, P]),
     "lg_conv2d_s2_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "lg_conv_stats_workspace_bytes": (Z, [I, I, I, I, I]),
-    "lg_conv2d_s2_fwd_stats": (I, [P, P, P, P, P, I, I, I, I, I, I, P, Z, P, P]),
+    "lg_conv_fwd_stats_fused": (I, [I, I, I, I, I, I, I]),
+    "lg_conv2d_s2_fwd_stats": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, Z, P, P]),
     "lg_conv2d_s2_dgrad_m16": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "lg_conv2d_s2_wgrad_m16": (I, [P, P, P, P, P, P, Z, I, I, I, I, I, I, I, P]),
     "lg_conv2d_s2_dgrad": (I, [P, P, P, I, I, I, I, I, I, P]),
     "lg_conv2d_s2_wgrad": (I, [P, P, P, P, Z, I, I, I, I, I, I, I, P]),
     "lg_convT_s2_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
-    "lg_convT_s2_fwd_stats": (I, [P, P, P, P, P, I, I, I, I, I, I, P, Z, P, P]),
+    "lg_convT_s2_fwd_stats": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, Z, P, P]),
     "lg_convT_s2_dgrad_m16": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "lg_convT_s2_wgrad_m16": (I, [P, P, P, P, P, P, Z, I, I, I, I, I, I, I, P]),
     "lg_convT_s2_dgrad": (I, [P, P, P, I, I, I, I, I, I, P]),
@@ -48,11 +49,14 @@ SIGNATURES = {
     "lg_instnorm_workspace_bytes": (Z, [I, L]),
     "lg_instnorm_stats_stride": (I, []),
     "lg_instnorm_leaky_stats": (I, [P, P, P, P, P, Z, I, L, I, F, P]),
+    "lg_instnorm_leaky_stats_z16": (I, [P, P, P, P, P, Z, I, L, I, F, P, P]),
     "lg_instnorm_stats_finalize": (I, [P, I, P, P, P, I, P]),
     "lg_instnorm_leaky_apply": (I, [P, P, P, P, P, I, L, I, I, F, P]),
     "lg_instnorm_leaky_bwd": (I, [P, P, P, I, P, P, P, P, P, Z, I, L, I, I, F, I, P]),
     "lg_instnorm_bwd_db_workspace_bytes": (Z, [I, L, I]),
     "lg_instnorm_leaky_bwd_db": (I, [P, P, P, I, P, P, P, P, P, I, P, Z, I, L, I, I, F, I, P]),
+    "lg_instnorm_leaky_apply_z16": (I, [P, P, P, I, P, P, I, L, I, I, F, P]),
+    "lg_instnorm_leaky_bwd_z16": (I, [P, P, P, I, P, P, P, P, P, I, P, Z, I, L, I, I, F, I, P]),
     "lg_dense_fwd": (I, [P, P, P, P, I, I, I, P]),
     "lg_dense_wgrad": (I, [P, P, P, P, I, I, I, I, P]),
     "lg_dense_dgrad": (I, [P, P, P, I, I, I, P]),

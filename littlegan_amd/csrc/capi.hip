@@ -33,8 +33,8 @@ extern "C" int lg_n3_p16_supported(int H, int W, int C);
 extern "C" int lg_n3_s1t_fwd_p16_try(const void* x16, const float* w, const float* bias, float* y, int B, int H, int W,
                                      int C, void* stream);
 extern "C" int lg_n3_up_p16_try(const void* src16, const float* w, float* out, int B, int H, int W, int C, void* stream);
-extern "C" int lg_n3_conv1_fwd_p16_try(const float* img, const float* w, const float* bias, float* z, int B, int H, int W,
-                                       int N, void* spart, size_t spart_bytes, int* nparts, void* stream);
+extern "C" int lg_n3_conv1_fwd_p16_try(const float* img, const float* w, const float* bias, float* z, void* z16, int B, int H,
+                                       int W, int N, void* spart, size_t spart_bytes, int* nparts, void* stream);
 extern "C" int lg_n3_s1_dgrad_p16_try(const float* dpre, const float* w, float* dx, void* dx16, int B, int H, int W, int N,
                                       void* stream);
 static bool n3_enabled() {
@@ -53,6 +53,20 @@ enum { MODE_DOWN = 0, MODE_UP = 1, MODE_S1T = 2, MODE_PATCH = 3 };
 
 static inline const void* up_pack(const void* pack, int cb, int cs, int dtype) {
   return (const char*)pack + lg_conv_pack_up_offset(cb, cs, dtype);
+}
+
+extern "C" int lg_conv_halo_supported(int mode, int dtype, int B, int Hm, int Wm, int Cs, int N);
+extern "C" int lg_n3_conv1_p16_supported(int H, int W, int N);
+
+// 1 if lg_conv2d_s2_fwd_stats (up == 0) / lg_convT_s2_fwd_stats (up == 1) on this shape returns fused moment partials
+// (*nparts > 0) when given a workspace of lg_conv_stats_workspace_bytes: the kernel's tiling puts one sample per block.
+// The bf16 activation path asks BEFORE the call, because only then may the conv write its result as bf16 alone.
+extern "C" int lg_conv_fwd_stats_fused(int up, int dtype, int B, int Hs, int Ws, int cb, int cs) {
+  if (B <= 0 || Hs <= 0 || Ws <= 0) return 0;
+  if (cb == 3) return (!up && dtype == LG_DT_BF16 && n3_enabled() && lg_n3_conv1_p16_supported(Hs, Ws, cs)) ? 1 : 0;
+  if (getenv("LG_NO_HALO")) return 0;
+  if ((long long)Hs * Ws < 128) return 0;  // several samples per 128-row tile: no per-sample record
+  return up ? lg_conv_halo_supported(1, dtype, B, Hs, Ws, cs, cb) : lg_conv_halo_supported(0, dtype, B, Hs, Ws, cb, cs);
 }
 
 // "down": big [B,2Hs,2Ws,cb] -> small [B,Hs,Ws,cs]
@@ -78,28 +92,33 @@ extern "C" int lg_conv2d_s2_fwd(const float* x, const void* pack, const float* b
 }
 // forward + fused InstanceNorm moment partials (finish with lg_instnorm_stats_finalize when *nparts > 0);
 // x16 (optional): bf16 mirror of x for the bf16 MFMA path
-extern "C" int lg_conv2d_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y, int B,
-                                      int Hs, int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes,
-                                      int* nparts, void* stream) {
+// y16 (optional, bf16 path): the result z is written as bf16 THERE instead of fp32 to y (y may then be null); the moment
+// partials are taken from the fp32 accumulators either way
+extern "C" int lg_conv2d_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y,
+                                      void* y16, int B, int Hs, int Ws, int cb, int cs, int dtype, void* spart,
+                                      size_t spart_bytes, int* nparts, void* stream) {
   if (nparts) *nparts = 0;
+  LG_CHECK_ARG(!y16 || dtype == LG_DT_BF16, "lg_conv2d_s2_fwd_stats: a bf16 result needs dtype bf16");
   if (cb == 3) {
     if (dtype == LG_DT_BF16 && n3_enabled()) {  // bf16 path: patch kernel with coalesced row stores + fused moments
-      const int rc = lg_n3_conv1_fwd_p16_try(x, raw_pack(pack, cb, cs, dtype), bias, y, B, Hs, Ws, cs, spart, spart_bytes,
-                                             nparts, stream);
+      const int rc = lg_n3_conv1_fwd_p16_try(x, raw_pack(pack, cb, cs, dtype), bias, y16 ? nullptr : y, y16, B, Hs, Ws, cs,
+                                             spart, spart_bytes, nparts, stream);
       if (rc != LG_ERR_UNSUPPORTED) return rc;
     }
-    return run_down(x, pack, bias, y, B, Hs, Ws, cb, cs, dtype, stream);
+    return lg_conv_igemm_ex(MODE_PATCH, dtype, x, nullptr, pack, bias, y16 ? nullptr : y, y16, B, Hs, Ws, 3, cs, 0, 2, 1, nullptr,
+                            0, nullptr, stream);
   }
-  return lg_conv_igemm_ex(MODE_DOWN, dtype, x, x16, pack, bias, y, nullptr, B, Hs, Ws, cb, cs, 0, 0, 0, spart, spart_bytes,
-                          nparts, stream);
+  return lg_conv_igemm_ex(MODE_DOWN, dtype, x, x16, pack, bias, y16 ? nullptr : y, y16, B, Hs, Ws, cb, cs, 0, 0, 0, spart,
+                          spart_bytes, nparts, stream);
 }
-extern "C" int lg_convT_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y, int B,
-                                     int Hs, int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes,
-                                     int* nparts, void* stream) {
+extern "C" int lg_convT_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y,
+                                     void* y16, int B, int Hs, int Ws, int cb, int cs, int dtype, void* spart,
+                                     size_t spart_bytes, int* nparts, void* stream) {
   if (nparts) *nparts = 0;
+  LG_CHECK_ARG(!y16 || (dtype == LG_DT_BF16 && cb != 3), "lg_convT_s2_fwd_stats: a bf16 result needs dtype bf16, cb != 3");
   if (cb == 3) return run_up(x, pack, bias, y, B, Hs, Ws, cb, cs, dtype, stream);
-  return lg_conv_igemm_ex(MODE_UP, dtype, x, x16, up_pack(pack, cb, cs, dtype), bias, y, nullptr, B, Hs, Ws, cs, cb, 0, 0, 0,
-                          spart, spart_bytes, nparts, stream);
+  return lg_conv_igemm_ex(MODE_UP, dtype, x, x16, up_pack(pack, cb, cs, dtype), bias, y16 ? nullptr : y, y16, B, Hs, Ws, cs, cb,
+                          0, 0, 0, spart, spart_bytes, nparts, stream);
 }
 // data / weight gradients with optional bf16 mirrors of their activation operands
 extern "C" int lg_conv2d_s2_dgrad_m16(const float* dy, const void* dy16, const void* pack, float* dx, void* dx16, int B,

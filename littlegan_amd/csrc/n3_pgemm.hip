@@ -308,16 +308,21 @@ extern "C" int lg_n3_up_p16_try(const void* src16, const float* w, float* out, i
   return LG_OK;
 }
 
+extern "C" int lg_n3_conv1_p16_supported(int H, int W, int N) { return (H % TS == 0 && W % TS == 0 && N == 64) ? 1 : 0; }
+
 // conv1 forward from the fp32 image (bf16 MFMA), with the per-block InstanceNorm moments; *nparts = records per sample
-extern "C" int lg_n3_conv1_fwd_p16_try(const float* img, const float* w, const float* bias, float* z, int B, int H, int W,
-                                       int N, void* spart, size_t spart_bytes, int* nparts, void* stream) {
+extern "C" int lg_n3_conv1_fwd_p16_try(const float* img, const float* w, const float* bias, float* z, void* z16, int B, int H,
+                                       int W, int N, void* spart, size_t spart_bytes, int* nparts, void* stream) {
   if (nparts) *nparts = 0;
-  if (H % TS || W % TS || N != 64 || !img || !w || !z) return LG_ERR_UNSUPPORTED;
+  if (H % TS || W % TS || N != 64 || !img || !w || (!z && !z16)) return LG_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int tpi = (H / TS) * (W / TS), ntiles = B * tpi;
   const dim3 grid(ntiles < 4096 ? ntiles : 4096);
   const bool stats = spart && nparts && (size_t)B * tpi * 3 * sizeof(double) <= spart_bytes;
-  if (stats) hipLaunchKernelGGL((patch_p16_kernel<2, 64, false, true>), grid, dim3(256), 0, st, img, w, bias, z, nullptr, (double*)spart, B, H, W, 1);
+  if (z16) {  // bf16 activation path: z leaves as bf16 (the moments still come from the fp32 accumulators)
+    if (stats) hipLaunchKernelGGL((patch_p16_kernel<2, 64, true, true>), grid, dim3(256), 0, st, img, w, bias, nullptr, (__bf16*)z16, (double*)spart, B, H, W, 1);
+    else hipLaunchKernelGGL((patch_p16_kernel<2, 64, true, false>), grid, dim3(256), 0, st, img, w, bias, nullptr, (__bf16*)z16, nullptr, B, H, W, 1);
+  } else if (stats) hipLaunchKernelGGL((patch_p16_kernel<2, 64, false, true>), grid, dim3(256), 0, st, img, w, bias, z, nullptr, (double*)spart, B, H, W, 1);
   else hipLaunchKernelGGL((patch_p16_kernel<2, 64, false, false>), grid, dim3(256), 0, st, img, w, bias, z, nullptr, nullptr, B, H, W, 1);
   LG_CHECK_LAUNCH("lg_n3_conv1_fwd_p16");
   if (stats) *nparts = tpi;

@@ -25,7 +25,8 @@ constexpr int EW_UNR = 4;    // float4 per thread per trip of the elementwise pa
 
 // partial[n][chunk] = {count, mean, M2} (doubles)
 __global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restrict__ x, double* __restrict__ partial,
-                                                            long long L, int nchunk, int pre_leaky, float alpha) {
+                                                            long long L, int nchunk, int pre_leaky, float alpha,
+                                                            __bf16* __restrict__ x16out) {
   const int n = blockIdx.y, ch = blockIdx.x;
   const long long base = (long long)n * L + (long long)ch * CHUNK;
   const long long lim = L - (long long)ch * CHUNK;  // valid elements in this chunk
@@ -39,6 +40,11 @@ __global__ __launch_bounds__(256) void stats_partial_kernel(const float* __restr
     v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (e < lim) {
       v[q] = *reinterpret_cast<const f32x4*>(x + base + e);
+      if (x16out) {  // bf16 activation path: the bf16 copy of the raw conv output is made in this same pass
+        bf16x4 w;
+        w[0] = (__bf16)v[q][0]; w[1] = (__bf16)v[q][1]; w[2] = (__bf16)v[q][2]; w[3] = (__bf16)v[q][3];
+        *reinterpret_cast<bf16x4*>(x16out + base + e) = w;
+      }
       if (pre_leaky) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[q][k] = lg_leaky(v[q][k], alpha);
@@ -297,6 +303,193 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 activation path ("z16"): in the bf16 MFMA configuration the raw conv output z lives in HBM as bf16 only (the
+// moments come from the fp32 accumulators of the conv epilogue, so they are unaffected), the skip tensors are the bf16
+// mirrors the encoder wrote anyway, and the gradients arrive as bf16.  These kernels move 8 elements (16 B of bf16) per
+// thread per access; fp32 operands, where one is mixed in, are two 16-B accesses.  L % 8 == 0.
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+struct f32x8 { f32x4 lo, hi; };
+
+template <bool IS16>
+__device__ __forceinline__ f32x8 load8(const void* p, long long i8) {  // elements [8*i8, 8*i8 + 8)
+  f32x8 r;
+  if constexpr (IS16) {
+    const bf16x8v w = *reinterpret_cast<const bf16x8v*>(reinterpret_cast<const __bf16*>(p) + i8 * 8);
+    r.lo = f32x4{(float)w[0], (float)w[1], (float)w[2], (float)w[3]};
+    r.hi = f32x4{(float)w[4], (float)w[5], (float)w[6], (float)w[7]};
+  } else {
+    const float* f = reinterpret_cast<const float*>(p) + i8 * 8;
+    r.lo = *reinterpret_cast<const f32x4*>(f);
+    r.hi = *reinterpret_cast<const f32x4*>(f + 4);
+  }
+  return r;
+}
+__device__ __forceinline__ void store8_bf16(__bf16* p, long long i8, const f32x8& v) {
+  bf16x8v w;
+  w[0] = (__bf16)v.lo[0]; w[1] = (__bf16)v.lo[1]; w[2] = (__bf16)v.lo[2]; w[3] = (__bf16)v.lo[3];
+  w[4] = (__bf16)v.hi[0]; w[5] = (__bf16)v.hi[1]; w[6] = (__bf16)v.hi[2]; w[7] = (__bf16)v.hi[3];
+  *reinterpret_cast<bf16x8v*>(p + i8 * 8) = w;
+}
+__device__ __forceinline__ void store8_f32(float* p, long long i8, const f32x8& v) {
+  *reinterpret_cast<f32x4*>(p + i8 * 8) = v.lo;
+  *reinterpret_cast<f32x4*>(p + i8 * 8 + 4) = v.hi;
+}
+
+constexpr int EW8_UNR = 4;  // 16-B accesses in flight per thread and stream
+
+// y = leaky(a*((z - mu_hi) - mu_lo) + beta) [+ skip]  from the bf16 z;  SK: 0 none, 1 fp32 skip, 2 bf16 skip
+template <int SK>
+__global__ __launch_bounds__(256) void apply16_kernel(const __bf16* __restrict__ x, const float* __restrict__ stats,
+                                                      const void* __restrict__ skip, float* __restrict__ y,
+                                                      __bf16* __restrict__ y16, long long L8, long long total8,
+                                                      int pre_leaky, int post_leaky, float alpha) {
+  const unsigned stride = gridDim.x * blockDim.x * EW8_UNR, tot = (unsigned)total8, l8 = (unsigned)L8;
+  for (unsigned i0 = blockIdx.x * blockDim.x * EW8_UNR + threadIdx.x; i0 < tot; i0 += stride) {
+    f32x8 v[EW8_UNR], sk[EW8_UNR];
+#pragma unroll
+    for (int u = 0; u < EW8_UNR; ++u) {
+      const unsigned i = i0 + u * 256;
+      if (i < tot) {
+        v[u] = load8<true>(x, i);
+        if constexpr (SK == 1) sk[u] = load8<false>(skip, i);
+        if constexpr (SK == 2) sk[u] = load8<true>(skip, i);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < EW8_UNR; ++u) {
+      const unsigned i = i0 + u * 256;
+      if (i >= tot) break;
+      const float* sp = stats + (long long)(i / l8) * LG_NSTAT;
+      const float mu = sp[0], a = sp[2], b = sp[3], mul = sp[4];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float t = k < 4 ? v[u].lo[k & 3] : v[u].hi[k & 3];
+        if (pre_leaky) t = lg_leaky(t, alpha);
+        t = a * ((t - mu) - mul) + b;
+        if (post_leaky) t = lg_leaky(t, alpha);
+        if constexpr (SK != 0) t += k < 4 ? sk[u].lo[k & 3] : sk[u].hi[k & 3];
+        if (k < 4) v[u].lo[k & 3] = t; else v[u].hi[k & 3] = t;
+      }
+      if (y) store8_f32(y, i, v[u]);
+      if (y16) store8_bf16(y16, i, v[u]);
+    }
+  }
+}
+
+// partial[n][blk] = {sum dz, sum dz*c} from the bf16 z; G16: gradient stored as bf16
+template <bool G16>
+__global__ __launch_bounds__(256) void bwd_partial16_kernel(const __bf16* __restrict__ x, const void* __restrict__ g,
+                                                            const float* __restrict__ stats, double* __restrict__ partial,
+                                                            long long L, int nchunk, int pre_leaky, int post_leaky,
+                                                            float alpha) {
+  const int n = blockIdx.y;
+  const float* sp = stats + (long long)n * LG_NSTAT;
+  const float mu = sp[0], a = sp[2], b = sp[3], mul = sp[4];
+  __shared__ double sred[32];
+  double s1 = 0.0, s2 = 0.0;
+  constexpr int CH8 = 2 * CHUNK;  // elements per block trip (256 threads x 4 x 8)
+  for (long long c0 = (long long)blockIdx.x * CH8; c0 < L; c0 += (long long)gridDim.x * CH8) {
+    const long long base8 = ((long long)n * L + c0) / 8;
+    const long long lim = L - c0;
+    f32x8 xv[4], gv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = (q * 256 + threadIdx.x) * 8;
+      if (e < lim) { xv[q] = load8<true>(x, base8 + e / 8); gv[q] = load8<G16>(g, base8 + e / 8); }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = (q * 256 + threadIdx.x) * 8;
+      if (e < lim) {
+        float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float xx = k < 4 ? xv[q].lo[k & 3] : xv[q].hi[k & 3];
+          if (pre_leaky) xx = lg_leaky(xx, alpha);
+          const float c = (xx - mu) - mul;
+          float dz = k < 4 ? gv[q].lo[k & 3] : gv[q].hi[k & 3];
+          if (post_leaky) dz = (a * c + b > 0.f) ? dz : alpha * dz;
+          q1 += dz;
+          q2 += dz * c;
+        }
+        s1 += (double)q1;
+        s2 += (double)q2;
+      }
+    }
+  }
+  double red[2] = {s1, s2};
+  lg_block_sum_d<2>(red, sred);
+  if (threadIdx.x == 0) {
+    double* o = partial + ((long long)n * nchunk + blockIdx.x) * 2;
+    o[0] = red[0]; o[1] = red[1];
+  }
+}
+
+// dz = a*(dy' - m1 - c*m2') from the bf16 z; DB: + column sums (bias gradient); the launch makes gridDim.x*256 a multiple
+// of C/8, so a thread meets the same 8 channels in every trip
+template <bool DB, bool G16>
+__global__ __launch_bounds__(256) void bwd_apply16_kernel(const __bf16* __restrict__ x, const void* __restrict__ g,
+                                                          const float* __restrict__ stats, const float* __restrict__ bstats,
+                                                          float* __restrict__ dx, __bf16* __restrict__ dx16, long long L8,
+                                                          long long total8, int pre_leaky, int post_leaky, float alpha,
+                                                          float* __restrict__ colpart, int C8) {
+  constexpr int UNR = DB ? 2 : EW8_UNR;  // DB: the extra loads of a trip sit gridDim.x*256 units apart (same channel octet)
+  const unsigned tot = (unsigned)total8, l8 = (unsigned)L8;
+  const unsigned ustep = DB ? gridDim.x * blockDim.x : 256u;                  // distance between a thread's units of one trip
+  const unsigned stride = DB ? gridDim.x * blockDim.x * UNR : gridDim.x * blockDim.x * UNR;
+  const unsigned first = DB ? blockIdx.x * blockDim.x + threadIdx.x : blockIdx.x * blockDim.x * UNR + threadIdx.x;
+  f32x8 csum;
+  csum.lo = f32x4{0.f, 0.f, 0.f, 0.f}; csum.hi = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (unsigned i0 = first; i0 < tot; i0 += stride) {
+    f32x8 xs[UNR], gs[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const unsigned i = i0 + u * ustep;
+      if (i < tot) { xs[u] = load8<true>(x, i); gs[u] = load8<G16>(g, i); }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const unsigned i = i0 + u * ustep;
+      if (i >= tot) break;
+      const int n = (int)(i / l8);
+      const float* sp = stats + (long long)n * LG_NSTAT;
+      const float mu = sp[0], a = sp[2], b = sp[3], mul = sp[4];
+      const float m1 = bstats[n * 4], m2 = bstats[n * 4 + 1], m1l = bstats[n * 4 + 2], m2l = bstats[n * 4 + 3];
+      f32x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float x0 = k < 4 ? xs[u].lo[k & 3] : xs[u].hi[k & 3];
+        float xx = x0;
+        if (pre_leaky) xx = lg_leaky(xx, alpha);
+        const float c = (xx - mu) - mul;
+        float dz = k < 4 ? gs[u].lo[k & 3] : gs[u].hi[k & 3];
+        if (post_leaky) dz = (a * c + b > 0.f) ? dz : alpha * dz;
+        float d = a * ((((dz - m1) - m1l) - c * m2) - c * m2l);
+        if (pre_leaky) d = (x0 > 0.f) ? d : alpha * d;
+        if (k < 4) o.lo[k & 3] = d; else o.hi[k & 3] = d;
+      }
+      if (dx) store8_f32(dx, i, o);
+      if (dx16) store8_bf16(dx16, i, o);
+      if constexpr (DB) { csum.lo += o.lo; csum.hi += o.hi; }
+    }
+  }
+  if constexpr (DB) {
+    __shared__ f32x4 sacc[512];
+    sacc[2 * threadIdx.x] = csum.lo; sacc[2 * threadIdx.x + 1] = csum.hi;
+    __syncthreads();
+    const int q = threadIdx.x;  // channel octet
+    if (q < C8) {
+      const int base = (int)(((long long)blockIdx.x * 256) % C8);
+      f32x4 tl = {0.f, 0.f, 0.f, 0.f}, th = {0.f, 0.f, 0.f, 0.f};
+      for (int k = (q - base + C8) % C8; k < 256; k += C8) { tl += sacc[2 * k]; th += sacc[2 * k + 1]; }
+      *reinterpret_cast<f32x4*>(colpart + ((long long)blockIdx.x * C8 + q) * 8) = tl;
+      *reinterpret_cast<f32x4*>(colpart + ((long long)blockIdx.x * C8 + q) * 8 + 4) = th;
+    }
+  }
+}
+
 // db[c] (+)= sum_k part[k][c]: 16 columns x 16 row groups per block, merged in group order (deterministic)
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ db, int nb,
                                                            int C, int accumulate) {
@@ -341,15 +534,26 @@ extern "C" size_t lg_instnorm_workspace_bytes(int B, long long L) {
 }
 
 // stats[B][8] = {mu_hi, sigma, a, beta, mu_lo, 0,0,0} of (pre_leaky ? leaky(x) : x), x = [B][L]
+extern "C" int lg_instnorm_leaky_stats_z16(const float* x, float* stats, const float* gamma, const float* beta,
+                                           void* workspace, size_t ws_bytes, int B, long long L, int pre_leaky,
+                                           float alpha, void* x16_out, void* stream);
 extern "C" int lg_instnorm_leaky_stats(const float* x, float* stats, const float* gamma, const float* beta,
                                        void* workspace, size_t ws_bytes, int B, long long L, int pre_leaky,
                                        float alpha, void* stream) {
+  return lg_instnorm_leaky_stats_z16(x, stats, gamma, beta, workspace, ws_bytes, B, L, pre_leaky, alpha, nullptr, stream);
+}
+// x16_out (may be null): also writes bf16(x) there — the bf16 activation path's copy of a conv output whose kernel had no
+// fused-moments epilogue (the fp32 x can then be dropped)
+extern "C" int lg_instnorm_leaky_stats_z16(const float* x, float* stats, const float* gamma, const float* beta,
+                                           void* workspace, size_t ws_bytes, int B, long long L, int pre_leaky,
+                                           float alpha, void* x16_out, void* stream) {
   LG_CHECK_ARG(x && stats && gamma && beta && workspace, "lg_instnorm_leaky_stats: null pointer");
   LG_CHECK_ARG(B > 0 && B <= 65535 && L > 0 && L % 4 == 0, "lg_instnorm_leaky_stats: bad shape B=%d L=%lld", B, L);
   LG_CHECK_ARG(ws_bytes >= lg_instnorm_workspace_bytes(B, L), "lg_instnorm_leaky_stats: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int nc = nchunks(L);
-  hipLaunchKernelGGL(stats_partial_kernel, dim3(nc, B), dim3(256), 0, st, x, (double*)workspace, L, nc, pre_leaky, alpha);
+  hipLaunchKernelGGL(stats_partial_kernel, dim3(nc, B), dim3(256), 0, st, x, (double*)workspace, L, nc, pre_leaky, alpha,
+                     (__bf16*)x16_out);
   LG_CHECK_LAUNCH("lg_instnorm_leaky_stats(partial)");
   hipLaunchKernelGGL(stats_final_kernel, dim3(B), dim3(64), 0, st, (const double*)workspace, stats, gamma, beta, nc);
   LG_CHECK_LAUNCH("lg_instnorm_leaky_stats(final)");
@@ -447,5 +651,102 @@ extern "C" int lg_instnorm_leaky_bwd_db(const float* x, const float* stats, cons
   hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)colpart, db, (int)nb, C,
                      accumulate);
   LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd_db(bias)");
+  return LG_OK;
+}
+
+// ---- bf16 activation path: the same ops reading the conv output z as bf16 (see the kernels above) -------------------
+// skip (may be null): fp32, or bf16 when skip_is_bf16
+extern "C" int lg_instnorm_leaky_apply_z16(const void* z16, const float* stats, const void* skip, int skip_is_bf16, float* y,
+                                           void* y16, int B, long long L, int pre_leaky, int post_leaky, float alpha,
+                                           void* stream) {
+  LG_CHECK_ARG(z16 && stats && (y || y16), "lg_instnorm_leaky_apply_z16: null pointer");
+  LG_CHECK_ARG(B > 0 && L > 0 && L % 8 == 0 && (long long)B * L / 8 < (1LL << 31),
+               "lg_instnorm_leaky_apply_z16: bad shape B=%d L=%lld", B, L);
+  const long long total8 = (long long)B * L / 8;
+  long long nb = (total8 + 256 * EW8_UNR - 1) / (256 * EW8_UNR);
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+  hipStream_t st = (hipStream_t)stream;
+  const __bf16* x = (const __bf16*)z16;
+  if (!skip)
+    hipLaunchKernelGGL(apply16_kernel<0>, dim3((int)nb), dim3(256), 0, st, x, stats, skip, y, (__bf16*)y16, L / 8, total8,
+                       pre_leaky, post_leaky, alpha);
+  else if (!skip_is_bf16)
+    hipLaunchKernelGGL(apply16_kernel<1>, dim3((int)nb), dim3(256), 0, st, x, stats, skip, y, (__bf16*)y16, L / 8, total8,
+                       pre_leaky, post_leaky, alpha);
+  else
+    hipLaunchKernelGGL(apply16_kernel<2>, dim3((int)nb), dim3(256), 0, st, x, stats, skip, y, (__bf16*)y16, L / 8, total8,
+                       pre_leaky, post_leaky, alpha);
+  LG_CHECK_LAUNCH("lg_instnorm_leaky_apply_z16");
+  return LG_OK;
+}
+
+// as lg_instnorm_leaky_bwd_db with x given as bf16 (workspace: lg_instnorm_bwd_db_workspace_bytes)
+extern "C" int lg_instnorm_leaky_bwd_z16(const void* z16, const float* stats, const void* g, int g_is_bf16, float* dx,
+                                         void* dx16, float* dgamma, float* dbeta, float* db, int C, void* workspace,
+                                         size_t ws_bytes, int B, long long L, int pre_leaky, int post_leaky, float alpha,
+                                         int accumulate, void* stream) {
+  LG_CHECK_ARG(z16 && stats && g && (dx || dx16) && workspace, "lg_instnorm_leaky_bwd_z16: null pointer");
+  LG_CHECK_ARG(B > 0 && B <= 65535 && L > 0 && L % 8 == 0 && (long long)B * L / 8 < (1LL << 31),
+               "lg_instnorm_leaky_bwd_z16: bad shape B=%d L=%lld", B, L);
+  LG_CHECK_ARG(ws_bytes >= lg_instnorm_workspace_bytes(B, L), "lg_instnorm_leaky_bwd_z16: workspace too small");
+  if (db) {
+    LG_CHECK_ARG(C > 0 && C % 8 == 0 && C / 8 <= 256 && L % C == 0 && (256 % (C / 8) == 0 || 768 % (C / 8) == 0),
+                 "lg_instnorm_leaky_bwd_z16: unsupported channel count C=%d (L=%lld)", C, L);
+    LG_CHECK_ARG(ws_bytes >= lg_instnorm_bwd_db_workspace_bytes(B, L, C), "lg_instnorm_leaky_bwd_z16: workspace too small");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const __bf16* x = (const __bf16*)z16;
+  int nc = 4096 / B;
+  if (nc < 1) nc = 1;
+  const int nch8 = (int)((L + 2 * CHUNK - 1) / (2 * CHUNK));
+  if (nc > nch8) nc = nch8;   // nch8 <= nchunks(L): the partial buffer is large enough
+  char* ws = (char*)workspace;
+  double* partial = (double*)ws;
+  float* bstats = (float*)(ws + part_bytes(B, L));
+  double* gsum = (double*)(ws + part_bytes(B, L) + bst_bytes(B));
+  if (g_is_bf16)
+    hipLaunchKernelGGL(bwd_partial16_kernel<true>, dim3(nc, B), dim3(256), 0, st, x, g, stats, partial, L, nc, pre_leaky,
+                       post_leaky, alpha);
+  else
+    hipLaunchKernelGGL(bwd_partial16_kernel<false>, dim3(nc, B), dim3(256), 0, st, x, g, stats, partial, L, nc, pre_leaky,
+                       post_leaky, alpha);
+  LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd_z16(partial)");
+  hipLaunchKernelGGL(bwd_final_kernel, dim3(B), dim3(64), 0, st, (const double*)partial, stats, bstats, gsum, L, nc);
+  LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd_z16(final)");
+  if (dgamma && dbeta) {
+    hipLaunchKernelGGL(bwd_affine_grad_kernel, dim3(1), dim3(256), 0, st, (const double*)gsum, dgamma, dbeta, B, accumulate);
+    LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd_z16(affine)");
+  }
+  const long long total8 = (long long)B * L / 8;
+  if (!db) {
+    long long nb = (total8 + 256 * EW8_UNR - 1) / (256 * EW8_UNR);
+    if (nb > 8192) nb = 8192;
+    if (nb < 1) nb = 1;
+    if (g_is_bf16)
+      hipLaunchKernelGGL((bwd_apply16_kernel<false, true>), dim3((int)nb), dim3(256), 0, st, x, g, stats, (const float*)bstats, dx,
+                         (__bf16*)dx16, L / 8, total8, pre_leaky, post_leaky, alpha, (float*)nullptr, 0);
+    else
+      hipLaunchKernelGGL((bwd_apply16_kernel<false, false>), dim3((int)nb), dim3(256), 0, st, x, g, stats, (const float*)bstats, dx,
+                         (__bf16*)dx16, L / 8, total8, pre_leaky, post_leaky, alpha, (float*)nullptr, 0);
+    LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd_z16(apply)");
+    return LG_OK;
+  }
+  const int C8 = C / 8, unit = 256 % C8 == 0 ? 1 : 3;
+  long long nb = (total8 + 511) / 512;   // two units per thread per trip
+  if (nb > DB_MAX_BLOCKS) nb = DB_MAX_BLOCKS;
+  if (nb < 1) nb = 1;
+  nb = (nb + unit - 1) / unit * unit;
+  float* colpart = (float*)(ws + lg_instnorm_workspace_bytes(B, L));   // [nb][C] floats, nb <= DB_MAX_BLOCKS (+2)
+  if (g_is_bf16)
+    hipLaunchKernelGGL((bwd_apply16_kernel<true, true>), dim3((int)nb), dim3(256), 0, st, x, g, stats, (const float*)bstats, dx,
+                       (__bf16*)dx16, L / 8, total8, pre_leaky, post_leaky, alpha, colpart, C8);
+  else
+    hipLaunchKernelGGL((bwd_apply16_kernel<true, false>), dim3((int)nb), dim3(256), 0, st, x, g, stats, (const float*)bstats, dx,
+                       (__bf16*)dx16, L / 8, total8, pre_leaky, post_leaky, alpha, colpart, C8);
+  LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd_z16(apply+bias)");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)colpart, db, (int)nb, C,
+                     accumulate);
+  LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd_z16(bias)");
   return LG_OK;
 }

@@ -132,8 +132,7 @@ class EagerTrainer:
             adj_t_img = torch.cat([img2, img1], 0)
             ctx_a: dict = {}
             # encoder(fake) was computed by D above with the same weights: hand its 4 maps to the Adjuster
-            i_d, f0 = a.init_dim, a.conv_filter[0]
-            tails = [ctx_d["enc"][k][0][B:] for k in (1, 2, 3)] + [ctx_d["heads_x"][B:].view(B, i_d, i_d, f0)]
+            tails = [m[B:] for m in ctx_d["enc_maps"]]  # fp32 maps (f32 path) / bf16 mirrors + the fp32 top map (bf16 path)
             # Adjuster input = [img1 ; fake]: with the encoder maps of `fake` handed over, only img1 is encoded here
             adj_image = A([img1, adj_in_cond], ctx_a, enc_tails=tails)
             ctx_d2: dict = {}

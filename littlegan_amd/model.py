@@ -118,8 +118,10 @@ class Encoder(_ConvStack):
         return cs
 
     def __call__(self, inputs, ctx: Optional[dict] = None, tails=None, keep_maps: bool = True):
-        """keep_maps=False: the caller only uses the LAST map; in the bf16 path the fp32 copies of maps 1-3 are then
-        not written where the next conv reads the bf16 mirror (their list entries are None).
+        """Returns the 4 maps (model.py:27).  f32 path: fp32 tensors.  bf16 path: maps 1-3 are the bf16 mirrors the next
+        conv reads anyway (they are also what the Adjuster's decoder adds as skips), map 4 (8x8, heads input) is fp32;
+        the raw conv outputs z are kept in HBM as bf16 only (moments from the fp32 accumulators of the conv epilogue).
+        keep_maps=False (f32 path): the caller only uses the LAST map.
         tails (optional): the 4 maps this encoder already produced for MORE samples that follow `inputs` in the
         batch (same weights); each returned map is then the pair (own map, tail) instead of a recomputation or a
         concatenated copy (the Adjuster's input is [img1 ; fake] and D has just encoded `fake`).  Every op is
@@ -129,27 +131,31 @@ class Encoder(_ConvStack):
         packs = self.packs()
         outs = []
         saved = []
-        B1 = x.shape[0]
         m16 = self.dtype == DT_BF16  # bf16 MFMA path: keep a bf16 mirror of every conv input (the operand image)
         x16 = None
         for i, (cb, cs) in enumerate(self.chans, 1):
             gm, bt = self._w[f"norm{i}.gamma"], self._w[f"norm{i}.beta"]
-            z, st = ops.conv2d_s2_fwd_stats(x, packs[i - 1], self._w[f"conv{i}.bias"], cs, self.dtype, gm, bt, x16=x16)
+            z, st = ops.conv2d_s2_fwd_stats(x, packs[i - 1], self._w[f"conv{i}.bias"], cs, self.dtype, gm, bt, x16=x16,
+                                            z16=m16, alpha=a)
             if st is None:  # kernel without the fused-moments epilogue (small maps, 3-channel input)
                 st = ops.instnorm_stats(z, gm, bt, 0, a)
-            h16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if m16 else None
-            if tails is None:
-                drop32 = (m16 and not keep_maps and i < 4 and ops.conv_halo_supported(
-                    0, self.dtype, z.shape[0], z.shape[1] // 2, z.shape[2] // 2, cs, self.chans[i][1]))
-                h = ops.instnorm_apply(z, st, None, 0, 1, a, out16=h16, want_f32=not drop32)
-                outs.append(h)
-            else:  # the map of the whole batch is the PAIR (own part, tail): no concatenated copy is made
-                h = ops.instnorm_apply(z, st, None, 0, 1, a, out16=h16)
-                outs.append((h, tails[i - 1]))
+            if m16:
+                h16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device)
+                # an fp32 copy only where something other than an MFMA operand load reads it: the top map (heads, first
+                # skip add) and inputs of shapes only the per-tap gather kernel covers
+                need32 = i == 4 or not ops.conv_halo_supported(0, self.dtype, z.shape[0], z.shape[1] // 2, z.shape[2] // 2, cs,
+                                                               self.chans[i][1])
+                h = ops.instnorm_apply(z, st, None, 0, 1, a, out16=h16, want_f32=need32)
+                m = h if i == 4 else h16
+            else:
+                h16 = None
+                h = m = ops.instnorm_apply(z, st, None, 0, 1, a)
+            outs.append(m if tails is None else (m, tails[i - 1]))  # pair (own part, tail): no concatenated copy is made
             saved.append((x, z, st, x16))
             x, x16 = h, h16
         if ctx is not None:
             ctx["enc"] = saved
+            ctx["enc_maps"] = outs
         return outs
 
     def backward(self, ctx, g_last, need_wgrad: bool, need_input_grad: bool, rows: Optional[slice] = None,
@@ -223,7 +229,8 @@ class Decoder(_ConvStack):
         x16 = x.to(torch.bfloat16) if m16 else None
         for i, (cb, cs) in enumerate(self.chans, 1):
             gm, bt = self._w[f"norm{i}.gamma"], self._w[f"norm{i}.beta"]
-            z, st = ops.convT_s2_fwd_stats(x, packs[i - 1], self._w[f"conv{i}.bias"], cb, self.dtype, gm, bt, x16=x16)
+            z, st = ops.convT_s2_fwd_stats(x, packs[i - 1], self._w[f"conv{i}.bias"], cb, self.dtype, gm, bt, x16=x16,
+                                           z16=m16, alpha=a)
             if st is None:
                 st = ops.instnorm_stats(z, gm, bt, 0, a)
             skip = add[i] if i < 4 else None
@@ -239,7 +246,7 @@ class Decoder(_ConvStack):
             h16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if want16 else None
             if isinstance(skip, tuple):  # skip given as (first rows, remaining rows) of the batch: one apply per part
                 b1 = skip[0].shape[0]
-                h = None if drop32 else torch.empty_like(z)
+                h = None if drop32 else torch.empty(z.shape, dtype=torch.float32, device=z.device)
                 for lo, hi, sk in ((0, b1, skip[0]), (b1, z.shape[0], skip[1])):
                     ops.instnorm_apply(z[lo:hi], st[lo:hi], sk, 0, 1, a, out=None if drop32 else h[lo:hi],
                                        out16=h16[lo:hi] if h16 is not None else None, want_f32=not drop32)
@@ -413,7 +420,10 @@ class _DenseHead:
         return [self.kernel, self.bias]
 
     def __call__(self, x):
-        return torch.sigmoid(ops.dense_fwd(x.contiguous(), self.kernel, self.bias))
+        o = self._o  # both heads come out of one fused kernel; this view returns its own columns
+        p = ops.heads_fwd(x.contiguous(), o._w["dense_pr.kernel"], o._w["dense_pr.bias"], o._w["dense_cond.kernel"],
+                          o._w["dense_cond.bias"])
+        return p[:, :1] if self._n == "dense_pr" else p[:, 1:]
 
 
 class Discriminator(_Module):

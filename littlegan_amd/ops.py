@@ -291,7 +291,8 @@ def conv_halo_supported(mode, dtype, B, Hm, Wm, Cs, N):
 
 
 # ------------------------------------------------------------------ instance norm
-def instnorm_stats(x, gamma, beta, pre_leaky, alpha, stats=None):
+def instnorm_stats(x, gamma, beta, pre_leaky, alpha, stats=None, x16_out=None):
+    """x16_out (optional bf16 tensor like x): also receives bf16(x) in the same pass."""
     B = x.shape[0]
     Ln = x.numel() // B
     _chk(x, name="x")
@@ -300,8 +301,10 @@ def instnorm_stats(x, gamma, beta, pre_leaky, alpha, stats=None):
     _chk(stats, (B, NSTAT), "stats")
     lib = _lib.load()
     ws = workspace(int(lib.lg_instnorm_workspace_bytes(B, Ln)), x.device, "small")
-    check(lib.lg_instnorm_leaky_stats(_p(x), _p(stats), _p(gamma), _p(beta), _p(ws), ws.numel(), B, Ln, int(pre_leaky),
-                                      float(alpha), _stream()), "lg_instnorm_leaky_stats")
+    if x16_out is not None:
+        _chk16(x16_out, x, "x16_out")
+    check(lib.lg_instnorm_leaky_stats_z16(_p(x), _p(stats), _p(gamma), _p(beta), _p(ws), ws.numel(), B, Ln, int(pre_leaky),
+                                          float(alpha), _p(x16_out), _stream()), "lg_instnorm_leaky_stats")
     return stats
 
 
@@ -312,13 +315,26 @@ def _chk16(t, like, name):
 
 
 def instnorm_apply(x, stats, skip, pre_leaky, post_leaky, alpha, out=None, out16=None, want_f32=True):
-    """want_f32=False: only the bf16 mirror out16 is written (returns None)."""
+    """want_f32=False: only the bf16 mirror out16 is written (returns None).
+    x may be the bf16 conv output of the bf16 activation path (then skip may be bf16 too)."""
     B = x.shape[0]
     Ln = x.numel() // B
-    _chk(x, name="x")
+    x_is16 = x.dtype == torch.bfloat16
+    if x_is16:
+        _chk16(x, x, "x")
+        if Ln % 8:
+            raise ValueError("instnorm_apply: a bf16 input needs a multiple of 8 elements per sample")
+    else:
+        _chk(x, name="x")
     _chk(stats, (B, NSTAT), "stats")
+    skip16 = skip is not None and skip.dtype == torch.bfloat16
     if skip is not None:
-        _chk(skip, name="skip")
+        if skip16:
+            if not x_is16:
+                raise ValueError("instnorm_apply: a bf16 skip needs the bf16 input path")
+            _chk16(skip, x, "skip")
+        else:
+            _chk(skip, name="skip")
         if skip.numel() != x.numel():
             raise ValueError("instnorm_apply: skip has a different size")
     if not want_f32:
@@ -327,23 +343,35 @@ def instnorm_apply(x, stats, skip, pre_leaky, post_leaky, alpha, out=None, out16
         out = None
     else:
         if out is None:
-            out = torch.empty_like(x)
+            out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         _chk(out, x.shape, "out")
     if out16 is not None:
         _chk16(out16, x, "out16")
-    check(_lib.load().lg_instnorm_leaky_apply(_p(x), _p(stats), _p(skip), _p(out), _p(out16), B, Ln, int(pre_leaky),
-                                              int(post_leaky), float(alpha), _stream()), "lg_instnorm_leaky_apply")
+    if x_is16:
+        check(_lib.load().lg_instnorm_leaky_apply_z16(_p(x), _p(stats), _p(skip), int(skip16), _p(out), _p(out16), B, Ln,
+                                                      int(pre_leaky), int(post_leaky), float(alpha), _stream()),
+              "lg_instnorm_leaky_apply_z16")
+    else:
+        check(_lib.load().lg_instnorm_leaky_apply(_p(x), _p(stats), _p(skip), _p(out), _p(out16), B, Ln, int(pre_leaky),
+                                                  int(post_leaky), float(alpha), _stream()), "lg_instnorm_leaky_apply")
     return out
 
 
 def instnorm_bwd(x, stats, g, dgamma, dbeta, pre_leaky, post_leaky, alpha, accumulate=False, out=None, out16=None,
                  want_f32=True, db=None):
-    """g may be fp32 or bf16 (as written by a bf16 data-gradient conv).  Returns the fp32 dx (or None if want_f32 is
-    False, in which case only the bf16 mirror out16 is written).  db [C] (optional, C = x.shape[-1]): receives the
-    column sums of dx = the bias gradient of the conv layer that produced x, in the same pass."""
+    """g may be fp32 or bf16 (as written by a bf16 data-gradient conv); x fp32, or the bf16 conv output of the bf16
+    activation path.  Returns the fp32 dx (or None if want_f32 is False, in which case only the bf16 mirror out16 is
+    written).  db [C] (optional, C = x.shape[-1]): receives the column sums of dx = the bias gradient of the conv
+    layer that produced x, in the same pass."""
     B = x.shape[0]
     Ln = x.numel() // B
-    _chk(x, name="x")
+    x_is16 = x.dtype == torch.bfloat16
+    if x_is16:
+        _chk16(x, x, "x")
+        if Ln % 8:
+            raise ValueError("instnorm_bwd: a bf16 input needs a multiple of 8 elements per sample")
+    else:
+        _chk(x, name="x")
     g16 = g.dtype == torch.bfloat16
     if g16:
         _chk16(g, x, "g")
@@ -354,7 +382,7 @@ def instnorm_bwd(x, stats, g, dgamma, dbeta, pre_leaky, post_leaky, alpha, accum
     _chk(stats, (B, NSTAT), "stats")
     if want_f32:
         if out is None:
-            out = torch.empty_like(x)
+            out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         _chk(out, x.shape, "out")
     else:
         if out16 is None:
@@ -368,9 +396,9 @@ def instnorm_bwd(x, stats, g, dgamma, dbeta, pre_leaky, post_leaky, alpha, accum
         C = x.shape[-1]
         _chk(db, (C,), "db")
     ws = workspace(int(lib.lg_instnorm_bwd_db_workspace_bytes(B, Ln, C)), x.device, "small")
-    check(lib.lg_instnorm_leaky_bwd_db(_p(x), _p(stats), _p(g), int(g16), _p(out), _p(out16), _p(dgamma), _p(dbeta), _p(db),
-                                       C, _p(ws), ws.numel(), B, Ln, int(pre_leaky), int(post_leaky), float(alpha),
-                                       int(accumulate), _stream()), "lg_instnorm_leaky_bwd_db")
+    fn = lib.lg_instnorm_leaky_bwd_z16 if x_is16 else lib.lg_instnorm_leaky_bwd_db
+    check(fn(_p(x), _p(stats), _p(g), int(g16), _p(out), _p(out16), _p(dgamma), _p(dbeta), _p(db), C, _p(ws), ws.numel(), B, Ln,
+             int(pre_leaky), int(post_leaky), float(alpha), int(accumulate), _stream()), "lg_instnorm_leaky_bwd")
     return out
 
 
@@ -487,17 +515,18 @@ def adam_advance(state, b1, b2):
 
 # ------------------------------------------------------------------ conv forward with fused InstanceNorm moments
 def _fwd_stats(fn_name, x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, tag, flops, up):
-    """Runs the conv; if its kernel produced per-block moment partials, finishes them into the stats record.
-    Returns stats [B, NSTAT] or None (caller then runs instnorm_stats on the output)."""
+    """Runs the conv (`out` fp32, or bf16 = the bf16 activation path); if its kernel produced per-block moment partials,
+    finishes them into the stats record.  Returns stats [B, NSTAT] or None (caller then runs instnorm_stats)."""
     import ctypes
     lib = _lib.load()
     ws = workspace(int(lib.lg_conv_stats_workspace_bytes(int(up), B, Hs, Ws, cb if up else cs)), out.device, "statpart")
     nparts = ctypes.c_int(0)
+    o16 = out.dtype == torch.bfloat16
     e0 = _pb()
     if x16 is not None:
         _chk16(x16, x if x is not None else x16, "x16")
-    check(getattr(lib, fn_name)(_p(x), _p(x16), _p(pack), _p(bias), _p(out), B, Hs, Ws, cb, cs, dtype, _p(ws), ws.numel(),
-                                ctypes.addressof(nparts), _stream()), fn_name)
+    check(getattr(lib, fn_name)(_p(x), _p(x16), _p(pack), _p(bias), 0 if o16 else _p(out), _p(out) if o16 else 0, B, Hs, Ws, cb,
+                                cs, dtype, _p(ws), ws.numel(), ctypes.addressof(nparts), _stream()), fn_name)
     _pe(e0, tag, flops)
     if nparts.value <= 0:
         return None
@@ -507,28 +536,64 @@ def _fwd_stats(fn_name, x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma
     return stats
 
 
-def conv2d_s2_fwd_stats(x, pack, bias, cs, dtype, gamma, beta, x16=None):
-    """conv2d_s2_fwd + the InstanceNormalization statistics of its output -> (y, stats or None)."""
+_FUSED_OK = {}
+
+
+def _fwd_stats_z16(fn_name, x, x16, pack, bias, shape, B, Hs, Ws, cb, cs, dtype, gamma, beta, tag, flops, up, alpha):
+    """bf16 activation path: z leaves the conv as bf16.  Where the conv kernel fuses the moments (from its fp32
+    accumulators) that is the only copy ever written; otherwise the conv writes fp32 once, the statistics pass reads it
+    and emits the bf16 copy in the same sweep, and the fp32 tensor is dropped.  Either way:
+    moments of the fp32 z, everything downstream reads bf16(z)."""
+    dev = bias.device
+    key = (int(up), dtype, B, Hs, Ws, cb, cs)
+    if key not in _FUSED_OK:
+        _FUSED_OK[key] = bool(_lib.load().lg_conv_fwd_stats_fused(*key))
+    if _FUSED_OK[key]:
+        z16 = torch.empty(shape, dtype=torch.bfloat16, device=dev)
+        st = _fwd_stats(fn_name, x, x16, pack, bias, z16, B, Hs, Ws, cb, cs, dtype, gamma, beta, tag, flops, up)
+        if st is None:
+            raise _lib.LittleGanHipError(f"{fn_name}: lg_conv_fwd_stats_fused promised fused moments for {key}, none came")
+        return z16, st
+    z = torch.empty(shape, dtype=torch.float32, device=dev)
+    st = _fwd_stats(fn_name, x, x16, pack, bias, z, B, Hs, Ws, cb, cs, dtype, gamma, beta, tag, flops, up)
+    if st is not None:  # (moments fused although not promised: keep them, cast once)
+        return z.to(torch.bfloat16), st
+    z16 = torch.empty(shape, dtype=torch.bfloat16, device=dev)
+    st = instnorm_stats(z, gamma, beta, 0, alpha, x16_out=z16)
+    return z16, st
+
+
+def conv2d_s2_fwd_stats(x, pack, bias, cs, dtype, gamma, beta, x16=None, z16=False, alpha=0.3):
+    """conv2d_s2_fwd + the InstanceNormalization statistics of its output -> (z, stats or None).
+    z16=True (bf16 dtype): z is returned as a bf16 tensor and stats is never None (see _fwd_stats_z16)."""
     B, H, W, cb = (x if x is not None else x16).shape  # x may be None when the bf16 mirror feeds the halo kernel
     if x is not None:
         _chk(x, name="x")
     _chk(bias, (cs,), "bias")
     if H % 2 or W % 2:
         raise ValueError("conv2d_s2_fwd_stats: H and W must be even")
+    tag, fl = "conv_igemm_patch" if cb == 3 else "conv_igemm_down", 50.0 * B * (H // 2) * (W // 2) * cb * cs
+    if z16:
+        return _fwd_stats_z16("lg_conv2d_s2_fwd_stats", x, x16, pack, bias, (B, H // 2, W // 2, cs), B, H // 2, W // 2, cb, cs,
+                              dtype, gamma, beta, tag, fl, False, alpha)
     out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.float32, device=bias.device)
-    st = _fwd_stats("lg_conv2d_s2_fwd_stats", x, x16, pack, bias, out, B, H // 2, W // 2, cb, cs, dtype, gamma, beta,
-                    "conv_igemm_patch" if cb == 3 else "conv_igemm_down", 50.0 * B * (H // 2) * (W // 2) * cb * cs, up=False)
+    st = _fwd_stats("lg_conv2d_s2_fwd_stats", x, x16, pack, bias, out, B, H // 2, W // 2, cb, cs, dtype, gamma, beta, tag, fl,
+                    up=False)
     return out, st
 
 
-def convT_s2_fwd_stats(x, pack, bias, cb, dtype, gamma, beta, x16=None):
+def convT_s2_fwd_stats(x, pack, bias, cb, dtype, gamma, beta, x16=None, z16=False, alpha=0.3):
     B, Hs, Ws, cs = (x if x is not None else x16).shape
     if x is not None:
         _chk(x, name="x")
     _chk(bias, (cb,), "bias")
+    fl = 50.0 * B * Hs * Ws * cb * cs
+    if z16:
+        return _fwd_stats_z16("lg_convT_s2_fwd_stats", x, x16, pack, bias, (B, 2 * Hs, 2 * Ws, cb), B, Hs, Ws, cb, cs, dtype,
+                              gamma, beta, "conv_igemm_up", fl, True, alpha)
     out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.float32, device=bias.device)
-    st = _fwd_stats("lg_convT_s2_fwd_stats", x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, "conv_igemm_up",
-                    50.0 * B * Hs * Ws * cb * cs, up=True)
+    st = _fwd_stats("lg_convT_s2_fwd_stats", x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, "conv_igemm_up", fl,
+                    up=True)
     return out, st
 
 
