@@ -47,6 +47,9 @@ class Cfg:
     partition_interval: int = 4
     train_adj: bool = True
     cond_dim: int = 7
+    # NOT a reference key: restate the bf16 MFMA configuration of the build under test (BASELINE.json configs[2]) —
+    # round to bfloat16 (RNE) exactly where its kernels do, everything else stays fp64.  See bf16_round / _q below.
+    emulate_bf16: bool = False
 
     @property
     def image_dim(self) -> int:  # model.py:83,101 + 4 stride-2 convT
@@ -69,6 +72,38 @@ def data_rescale(x):
 def inverse_rescale(y):
     """utils.py:55-56 (tf.round = round-half-to-even, like np.round)"""
     return np.round((np.asarray(y, F64) + 1.0) * 127.5)
+
+
+# --------------------------------------------------------------------------
+# bf16 emulation (test infrastructure for the bf16 MFMA path; the reference itself is fp32 throughout).
+# The build's bf16 configuration rounds (round-to-nearest-even, fp32 -> bf16) at these points and nowhere else:
+#   * every 5x5 conv / transposed-conv OPERAND: the layer input (activation mirror, 3-channel image, or the incoming
+#     gradient dz / dpre of a data- or weight-gradient contraction) and the kernel;
+#   * the raw conv output z as it is stored (the InstanceNorm MOMENTS are taken from the unrounded accumulators, the
+#     normalisation and both norm-backward passes read the rounded z);
+#   * the data gradients handed from one 5x5 layer to the next level's norm backward (not the image gradient, not the
+#     gradient that leaves the decoder towards the dense layer).
+# Accumulation (fp32 in the kernels) and everything outside the 5x5 layers (dense, heads, losses, Adam) is fp64 here.
+# With this mode on, a bf16 kernel bug shows as an O(1e-2) mismatch instead of hiding under an O(1e-1) tolerance.
+# --------------------------------------------------------------------------
+def bf16_round(x):
+    """fp64 -> fp32 (RNE) -> bf16 (RNE) -> fp64, elementwise."""
+    a = np.ascontiguousarray(np.asarray(x, F64).astype(np.float32))
+    u = a.view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).astype(np.uint32)
+    return r.view(np.float32).astype(F64)
+
+
+def _q(cfg, x):
+    return bf16_round(x) if getattr(cfg, "emulate_bf16", False) else x
+
+
+TRACE = None  # diagnostics: set to a list to record (tag, array) for the backward intermediates
+
+
+def _trace(tag, a):
+    if TRACE is not None and a is not None:
+        TRACE.append((tag, np.array(a)))
 
 
 # --------------------------------------------------------------------------
@@ -178,12 +213,15 @@ def sigmoid(x):
 IN_EPS = 1e-3
 
 
-def instnorm(x, gamma, beta, eps=IN_EPS):
+def instnorm(x, gamma, beta, eps=IN_EPS, xq=None):
+    """xq (bf16 emulation only): the stored (rounded) copy of x that is normalised; the moments are those of x."""
     B = x.shape[0]
     xf = x.reshape(B, -1)
     mu = xf.mean(axis=1, keepdims=True)
     c = xf - mu
     sigma = np.sqrt((c * c).mean(axis=1, keepdims=True))  # K.std: population std
+    if xq is not None:
+        c = xq.reshape(B, -1) - mu
     s = sigma + eps
     y = gamma * (c / s) + beta
     return y.reshape(x.shape), (c, sigma, s)
@@ -323,11 +361,15 @@ def train_weight_indices(cfg: Cfg, model: str, batch_no: int) -> List[int]:
 def encoder_fwd(cfg, We, x):
     """Encoder.call model.py:18-27 (dropout at :25 is identity: training=False default)."""
     outs, caches = [], []
+    emu = getattr(cfg, "emulate_bf16", False)
     for i in range(4):
         k, b, g, be = We[4 * i:4 * i + 4]
-        z = conv2d(x, k, b, 2)
-        y, nc = instnorm(z, g[0], be[0])
+        x = _q(cfg, x)  # MFMA operand (bf16 emulation; identity otherwise)
+        z = conv2d(x, _q(cfg, k), b, 2)
+        y, nc = instnorm(z, g[0], be[0], xq=_q(cfg, z) if emu else None)
         h = leaky(y, cfg.leaky_alpha)
+        if emu and i < 3:
+            h = bf16_round(h)  # maps 1-3 exist only as the bf16 mirrors (next conv operand, Adjuster skip); map 4 is fp32
         caches.append((x, y, nc))
         outs.append(h)
         x = h
@@ -345,10 +387,15 @@ def encoder_bwd(cfg, We, caches, d_outs, need_wgrad=True, need_input_grad=False)
             g_h = d_outs[i] if g_h is None else g_h + d_outs[i]
         dy = leaky_bwd(y, g_h, cfg.leaky_alpha)
         dz, dg, dbe = instnorm_bwd(nc, g[0], dy)
+        dzq = _q(cfg, dz)  # MFMA operand of the data- and weight-gradient contractions; the bias sums use dz itself
         want_dx = (i > 0) or need_input_grad
-        dx = conv_bwd_input(dz, k, 2, x.shape[1:3]) if want_dx else None
+        dx = conv_bwd_input(dzq, _q(cfg, k), 2, x.shape[1:3]) if want_dx else None
+        if dx is not None and i > 0:
+            dx = _q(cfg, dx)  # inter-layer gradients are stored as bf16; the image gradient (level 1) is fp32
+        _trace(f"enc{i + 1}.dz", dz)
+        _trace(f"enc{i + 1}.dx", dx)
         if need_wgrad:
-            grads[4 * i] = conv_bwd_filter(x, dz, 2, k.shape[0])
+            grads[4 * i] = conv_bwd_filter(x, dzq, 2, k.shape[0])
             grads[4 * i + 1] = dz.sum(axis=(0, 1, 2))
             grads[4 * i + 2] = np.array([dg])
             grads[4 * i + 3] = np.array([dbe])
@@ -363,8 +410,9 @@ def decoder_fwd(cfg, Wd, x, add):
         k, b, g, be = Wd[4 * i:4 * i + 4]
         if add[i] is not None:
             x = x + add[i]
-        z = conv2d_transpose(x, k, b, 2)
-        y, nc = instnorm(z, g[0], be[0])
+        x = _q(cfg, x)  # MFMA operand
+        z = conv2d_transpose(x, _q(cfg, k), b, 2)
+        y, nc = instnorm(z, g[0], be[0], xq=_q(cfg, z) if getattr(cfg, "emulate_bf16", False) else None)
         h = leaky(y, cfg.leaky_alpha)
         caches.append((x, y, nc))
         x = h
@@ -381,7 +429,12 @@ def decoder_bwd(cfg, Wd, caches, g_h, need_wgrad=True):
         x, y, nc = caches[i]
         dy = leaky_bwd(y, g_h, cfg.leaky_alpha)
         dz, dg, dbe = instnorm_bwd(nc, g[0], dy)
-        dx, dw, db = conv2d_transpose_bwd(x, k, dz, 2)
+        dx, dw, _ = conv2d_transpose_bwd(x, _q(cfg, k), _q(cfg, dz), 2)
+        db = dz.sum(axis=(0, 1, 2))
+        if i > 0:
+            dx = _q(cfg, dx)  # bf16 between the levels; fp32 where it leaves the decoder (dense layer)
+        _trace(f"dec{i + 1}.dz", dz)
+        _trace(f"dec{i + 1}.dx", dx)
         if need_wgrad:
             grads[4 * i:4 * i + 4] = [dw, db, np.array([dg]), np.array([dbe])]
         g_h = dx
@@ -396,7 +449,8 @@ def generator_fwd(cfg, Wg, noise, cond):
     v4 = v.reshape(-1, cfg.init_dim, cfg.init_dim, cfg.conv_filter[0])
     w, nc = instnorm(v4, Wg[2][0], Wg[3][0])
     xdec, dcaches = decoder_fwd(cfg, Wg[4:20], w, [None] * 4)
-    pre = conv2d_transpose(xdec, Wg[20], Wg[21], 1)
+    xdec = _q(cfg, xdec)
+    pre = conv2d_transpose(xdec, _q(cfg, Wg[20]), Wg[21], 1)
     img = np.tanh(pre)
     return img, (x0, u, nc, dcaches, xdec, img)
 
@@ -405,8 +459,11 @@ def generator_bwd(cfg, Wg, cache, d_img):
     x0, u, nc, dcaches, xdec, img = cache
     grads = [None] * 22
     dpre = d_img * (1.0 - img * img)
-    dxdec, dwf, dbf = conv2d_transpose_bwd(xdec, Wg[20], dpre, 1)
-    grads[20], grads[21] = dwf, dbf
+    dxdec, dwf, _ = conv2d_transpose_bwd(xdec, _q(cfg, Wg[20]), _q(cfg, dpre), 1)
+    dxdec = _q(cfg, dxdec)
+    _trace("final.dpre", dpre)
+    _trace("final.dx", dxdec)
+    grads[20], grads[21] = dwf, dpre.sum(axis=(0, 1, 2))
     dgrads, dw4 = decoder_bwd(cfg, Wg[4:20], dcaches, dxdec)
     grads[4:20] = dgrads
     dv4, dg, dbe = instnorm_bwd(nc, Wg[2][0], dw4)
@@ -451,7 +508,7 @@ def adjuster_fwd(cfg, W, image, cond):
     w4 = w2.reshape(-1, cfg.init_dim, cfg.init_dim, cfg.conv_filter[0])
     add = outs[::-1]  # encoder_layers.reverse()  model.py:133
     xdec, dcaches = decoder_fwd(cfg, Wg[4:20], w4, add)
-    pre = conv2d_transpose(xdec, Wg[20], Wg[21], 1)
+    pre = conv2d_transpose(_q(cfg, xdec), _q(cfg, Wg[20]), Wg[21], 1)
     img = np.tanh(pre)
     return img, (cond, u, nc, dcaches, img)
 
@@ -461,7 +518,7 @@ def adjuster_bwd_own(cfg, W, cache, d_img):
     Wg, Wa = W["G"], W["A"]
     cond, u, nc, dcaches, img = cache
     dpre = d_img * (1.0 - img * img)
-    dxdec = conv_fwd(dpre, Wg[20], 1)
+    dxdec = _q(cfg, conv_fwd(_q(cfg, dpre), _q(cfg, Wg[20]), 1))
     _, dw4 = decoder_bwd(cfg, Wg[4:20], dcaches, dxdec, need_wgrad=False)
     dv, dg, dbe = instnorm_bwd(nc, Wa[2][0], dw4.reshape(u.shape))
     du = leaky_bwd(u, dv, cfg.leaky_alpha)
@@ -519,8 +576,15 @@ class TrainState:
                     "A": AdamState(c.lr, 0.9, 0.999, 4)}  # eager_trainer.py:30 defaults
 
 
-def step_gradients(cfg: Cfg, W, batch_no: int, inp: Dict[str, np.ndarray]):
-    """The arithmetic of eager_trainer.py:133-163 up to (not including) the optimizer
+def step_gradients(cfg: Cfg, W, batch_no: int, inp: Dict[str, np.ndarray], fake_override=None, adj_override=None):
+    """fake_override / adj_override (bf16-emulation tests only): images produced by the implementation under test,
+    used downstream INSTEAD of this oracle's own generator / adjuster outputs (which are still computed, returned as
+    fake_image_own / adj_image_own, and provide the caches of the generator / adjuster backward).  With bf16 rounding
+    inside every layer, a 1e-5 difference between two implementations' images flips a fraction of the roundings in
+    everything computed from them and decorrelates the two discriminator passes at the 1e-2 level; handing over the
+    image at the model boundary keeps the comparison of each model's gradients tight.
+
+    The arithmetic of eager_trainer.py:133-163 up to (not including) the optimizer
     applies.  `inp` holds real_image_1, real_cond_1, real_image_2, real_cond_2,
     noise, new_image (the RNG-dependent step inputs are inputs: SURVEY.md a17).
     Returns dict with fake_image, adj_image, losses and the three FULL gradient lists
@@ -529,6 +593,10 @@ def step_gradients(cfg: Cfg, W, batch_no: int, inp: Dict[str, np.ndarray]):
     noise, new_image = inp["noise"], inp["new_image"]
     out = {}
     fake, gcache = generator_fwd(cfg, W["G"], noise, c2)
+    out["fake_image_own"] = fake
+    if fake_override is not None:
+        fake = np.asarray(fake_override, F64)
+        gcache = gcache[:-1] + (fake,)
     (real_pr, real_c), rcache = discriminator_fwd(cfg, W["D"], new_image)
     (fake_pr, fake_c), fcache = discriminator_fwd(cfg, W["D"], fake)
     # eager_trainer.py:85-91
@@ -554,6 +622,10 @@ def step_gradients(cfg: Cfg, W, batch_no: int, inp: Dict[str, np.ndarray]):
         adj_in_img = np.concatenate([img1, fake], 0)
         adj_t_img = np.concatenate([img2, img1], 0)
         adj_img, acache = adjuster_fwd(cfg, W, adj_in_img, adj_in_cond)
+        out["adj_image_own"] = adj_img
+        if adj_override is not None:
+            adj_img = np.asarray(adj_override, F64)
+            acache = acache[:-1] + (adj_img,)
         (adj_pr, adj_c), dcache = discriminator_fwd(cfg, W["D"], adj_img)
         adj_loss = (bce_mean(soft(1.0), adj_pr) + bce_mean(adj_t_cond, adj_c)
                     + cfg.l1_lambda * l1_mean(adj_t_img, adj_img))  # eager_trainer.py:98-102

@@ -8,8 +8,16 @@ Stated tolerances (parity to TensorFlow itself is UNPINNED, see oracle/np_oracle
                   The gap between the two is not arithmetic noise: LeakyReLU'(z) is discontinuous, and a
                   pre-activation within fp32 rounding of 0 takes the other branch than in fp64 (measured: one such
                   element among 2.6e5 moves a whole tape's gradients by 7e-4 rms; gpurun_out/diag10 of round 1).
-  bf16 MFMA path: pixels 4e-2 abs, losses 2e-2 rel, gradients median 0.15, every tensor 0.5 rms
-                  (bf16 operands carry 8 mantissa bits; accumulation is f32).
+  bf16 MFMA path: against the fp64 oracle (loose, secondary): pixels 6e-2 abs, losses 2e-2 rel, gradients median 0.2,
+                  every tensor 0.5 rms (bf16 operands carry 8 mantissa bits; accumulation is f32).
+                  Against the bf16-EMULATING oracle (O.Cfg.emulate_bf16: rounds exactly where the kernels round, fed with
+                  the kernels' own generated / adjusted images at the model boundaries): losses 2e-3 rel, every gradient
+                  tensor 8e-2 rms, median 4e-2.  That is the floor of ANY whole-step comparison in bf16, not kernel error:
+                  a 1e-6 difference ahead of a bf16 rounding flips a fraction of the roundings, and three layers later the
+                  two sides are decorrelated at the bf16 noise level (measured 1e-2 .. 3.5e-2 rms, growing with the number
+                  of layers a tensor's gradient has crossed; tests/diagnostics/emu_bf16_report.py).  The TIGHT check of
+                  the bf16 path is call by call: tests/test_step_replay_gpu.py (<= 6e-4 / 2e-5 rms for every kernel call of
+                  the step on its own inputs) and tests/test_launch_shapes_gpu.py (the benchmarked batch sizes).
 """
 import os
 from types import SimpleNamespace
@@ -23,7 +31,30 @@ from oracle import np_oracle as O
 pytestmark = pytest.mark.gpu
 
 TOLS = {"f32": dict(img=2e-5, loss=2e-5, grad_med=2e-5, grad_rms=5e-3, sfloor=2e-4),
-        "bf16": dict(img=4e-2, loss=2e-2, grad_med=0.15, grad_rms=0.5, sfloor=0.1)}
+        "bf16": dict(img=6e-2, loss=2e-2, grad_med=0.2, grad_rms=0.5, sfloor=0.4),   # vs fp64: loose, secondary
+        "bf16_emu": dict(img=4e-2, loss=2e-3, grad_med=4e-2, grad_rms=8e-2, sfloor=6e-2)}
+
+
+def emu_reference(cfg, W, b, inp, fake, adj):
+    """The bf16-emulating oracle on the same step, fed with the kernels' own images at the model boundaries."""
+    cfg_e = O.Cfg(**{**cfg.__dict__, "emulate_bf16": True})
+    return O.step_gradients(cfg_e, W, b, inp, fake_override=fake.detach().cpu().double().numpy(),
+                            adj_override=None if adj is None else adj.detach().cpu().double().numpy())
+
+
+def check_emu(tr, cfg, W, b, inp, fake, adj, lg, ld, la, only=None):
+    tol = TOLS["bf16_emu"]
+    ref = emu_reference(cfg, W, b, inp, fake, adj)
+    assert np.abs(fake.cpu().numpy() - ref["fake_image_own"]).max() < tol["img"]
+    pairs = [(lg, "gen_loss"), (ld, "disc_loss")]
+    sets = [("D", "dD"), ("G", "dG")]
+    if adj is not None:
+        assert np.abs(adj.cpu().numpy() - ref["adj_image_own"]).max() < tol["img"]
+        pairs.append((la, "adj_loss"))
+        sets.append(("A", "dA"))
+    for got, key in pairs:
+        assert abs(got.item() - ref[key]) < tol["loss"] * abs(ref[key]), (key, got.item(), ref[key])
+    check_grads(tr, ref, sets, tol, tag=f"emu b={b}", only=only)
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "step_small.npz")
 
 
@@ -110,6 +141,7 @@ def test_step_matches_oracle_small(mfma):
     tr = build(cfg, W, mfma)
     for b in (4, 5, 11, 15):
         inp = f32_round(O.make_inputs(cfg, cfg.batch_size, seed=50 + b))
+        W_before = {m: [w.copy() for w in ws] for m, ws in st.W.items()}
         ref = O.train_step(st, b, inp)
         fake, adj, lg, ld, la = tr.train_step_from_inputs(b, dev_inputs(inp))
         assert np.abs(fake.cpu().numpy() - ref["fake_image"]).max() < tol["img"]
@@ -123,6 +155,9 @@ def test_step_matches_oracle_small(mfma):
         else:
             assert adj is None and la is None
         check_grads(tr, ref, sets, tol, tag=f"b={b}", only={m: O.train_weight_indices(cfg, m, b) for m in "GDA"})
+        if mfma == "bf16":
+            check_emu(tr, cfg, {m: [w.copy() for w in ws] for m, ws in W_before.items()}, b, inp, fake, adj, lg, ld, la,
+                      only={m: O.train_weight_indices(cfg, m, b) for m in "GDA"})
         if mfma == "f32":
             # weights after Adam: a per-element update is O(lr); a near-zero gradient may take the other sign
             for m, dst in (("G", tr.generator.weights), ("D", tr.discriminator.weights), ("A", tr.adjuster.weights[16:20])):
@@ -197,6 +232,8 @@ def test_step_full_channels_one_step(mfma, init_dim):
     for got, key in ((lg, "gen_loss"), (ld, "disc_loss"), (la, "adj_loss")):
         assert abs(got.item() - ref[key]) < tol["loss"] * abs(ref[key])
     check_grads(tr, ref, (("D", "dD"), ("G", "dG"), ("A", "dA")), tol)
+    if mfma == "bf16":
+        check_emu(tr, cfg, W, 11, inp, fake, adj, lg, ld, la)
 
 
 def test_checkpoint_resume_is_bit_exact(tmp_path):
