@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["capi.hip", "conv_igemm.hip", "conv_halo.hip", "n3_kernels.hip", "n3_pgemm.hip", "wgrad_igemm.hip", "pack.hip", "norm.hip", "dense.hip", "heads.hip", "loss_optim.hip", "augment.hip"]
+SOURCES = ["capi.hip", "conv_igemm.hip", "conv_halo.hip", "conv_down3.hip", "n3_kernels.hip", "n3_pgemm.hip", "wgrad_igemm.hip", "pack.hip", "norm.hip", "dense.hip", "heads.hip", "loss_optim.hip", "augment.hip"]
 LIB = os.path.join(PKG, "liblittlegan_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
@@ -28,7 +28,7 @@ def build(force=False, verbose=True):
         s = os.path.join(HERE, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + os.environ.get("LG_EXTRA_FLAGS", "").split() + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

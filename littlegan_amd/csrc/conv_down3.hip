@@ -1,0 +1,294 @@
+// Software-pipelined stride-2 "down" contraction for gfx950, bf16 operands / fp32 accumulation:
+//   out[n][y][x][co] = bias[co] + sum_{ky,kx,ci} src[n][2y+ky-1][2x+kx-1][ci] * W[ky][kx][ci][co]        (TF SAME, k5 s2)
+// = Conv2D forward (model.py:15) and the data gradient of Conv2DTranspose (model.py:39-40), for the layers whose
+// small map is at least 8 x 16 pixels and whose N is a multiple of 128 (conv2 / conv3 forward, convT3 / convT2 dgrad).
+//
+// Why a second kernel next to conv_halo.hip: there a block's phases (halo staging, weight-fragment fetch, MFMAs,
+// epilogue) run one after the other and only other resident blocks fill the gaps — measured on conv2 forward (B = 256):
+// 160 us of which the MFMAs need 43.  Here the phases of ONE block overlap:
+//   * persistent blocks (2 per CU) walk a list of (pixel tile, column tile) items;
+//   * the source halo of a tile lives in LDS in 16-channel slices, DOUBLE-buffered: while the 25 taps of slice c run out
+//     of one buffer, the 16-B pieces of slice c+1 (or of the next item's first slice) are in flight global -> registers
+//     and are written to the other buffer behind the taps; one barrier per slice;
+//   * the weight fragments (1 KiB per tap, fragment order of pack.hip, straight global -> registers) are fetched one
+//     whole slice ahead: the 25 fragments of slice c+1 are requested while slice c computes (25 KiB in flight per wave);
+//   * halo rows are 32 B of data in a 48-B pitch and a pixel row is stored de-interleaved (even columns, then odd ones),
+//     so every A-fragment address of a tap is the lane's base plus a COMPILE-TIME offset (no address arithmetic in
+//     the tap loop) and ds_read_b128 is conflict-free (16 consecutive rows x 48 B hit 16 distinct 16-B slots);
+//   * the product is formed transposed (channels on the accumulator rows, pixels on the lanes): a lane then holds 4
+//     consecutive channels of its pixel per register group, the tile leaves the registers through the idle halo buffer
+//     with 8-byte LDS writes and reaches HBM as whole 256-B pixel rows, 16 B per lane;
+//   * the InstanceNormalization moments of the tile ({count, mean, M2}, instance.py:114-115) come out of the same
+//     registers, so no pass re-reads the output.
+#include <stdlib.h>
+#include <type_traits>
+#include "lg_common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16;                 // output tile (pixels)
+constexpr int HH = 2 * TH + 3;                 // halo rows  (19)
+constexpr int HWH = 18, HWP = 2 * HWH;         // halo pixel row: 18 even + 18 odd column slots (35 used)
+constexpr int NROWS = HH * HWP;                // 684 halo pixels per tile
+constexpr int ROWB = 48;                       // LDS pitch of a halo pixel (32 B of channels + 16 B)
+constexpr int HB = NROWS * ROWB;               // 32832 B per buffer
+constexpr int NPIECE = NROWS * 2;              // 16-B pieces per slice
+constexpr int PPT = (NPIECE + 255) / 256;      // pieces per thread (6)
+constexpr int KC = 16;                         // channels per slice = one MFMA k-step
+constexpr int NTAP = 25;
+constexpr int SRED_OFF = 2 * HB;               // 16 doubles of reduction scratch behind the two buffers
+constexpr int LDS_BYTES = 2 * HB + 256;
+
+struct D3Params {
+  const __bf16* src;   // [B][Hs][Ws][Cs] bf16
+  const char* wp;      // fragment-ordered pack [25][N32][KB][64][16 B]
+  const float* bias;   // [N] or null
+  __bf16* out;         // [B][Hm][Wm][N] bf16
+  double* spart;       // [B][nparts][3] or null
+  int B, Hs, Ws, Cs, Hm, Wm, N, N32, KB;
+  int tpi_x, tpi, ntn, nitems, nparts;
+};
+
+__device__ __forceinline__ int pix32(int r) {  // MFMA row -> tile pixel inside its 32-pixel group (see conv_halo.hip)
+  const int q = r >> 2, lo = r & 3;
+  const int odd = (q ^ (q >> 1) ^ (q >> 2)) & 1;
+  const int rank = odd ? ((q == 1) ? 0 : (q == 2) ? 1 : (q == 4) ? 2 : 3) : ((q == 0) ? 0 : (q == 3) ? 1 : (q == 5) ? 2 : 3);
+  return odd * 16 + rank * 4 + lo;
+}
+
+constexpr int toff_bytes(int t) {  // tap t = ky*5+kx: LDS byte offset of its source pixel relative to the lane's base
+  return ((t / 5) * HWP + ((t % 5) >> 1) + ((t % 5) & 1) * HWH) * ROWB;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* sred = reinterpret_cast<double*>(smem + SRED_OFF);
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: the weight addresses stay in SGPRs
+  const int G = gridDim.x;
+  const int lb = lg_xcd_remap(blockIdx.x, G);
+  const int nmine = (p.nitems - lb + G - 1) / G;  // items lb, lb + G, ...   (grid <= nitems)
+  const int nchunk = p.Cs / KC;
+  const int total = nmine * nchunk;
+
+  // ---- the (up to) 6 halo pieces this thread stages in every slice: LDS offset and position inside the halo ----------
+  int pl[PPT], pyx[PPT];
+#pragma unroll
+  for (int u = 0; u < PPT; ++u) {
+    const int q = tid + u * 256;
+    pl[u] = -1; pyx[u] = 0;
+    if (q < NPIECE) {
+      const int row = q >> 1, hy = row / HWP, hxp = row - hy * HWP;
+      const int hx = hxp < HWH ? 2 * hxp : 2 * (hxp - HWH) + 1;
+      pl[u] = row * ROWB + (q & 1) * 16;
+      pyx[u] = hx < 2 * TW + 3 ? (hy << 8) | hx : (0x7fff << 8);  // the 36th slot of a row is padding: never valid
+    }
+  }
+  const int half8 = (tid & 1) * 8;  // channel offset of this thread's pieces inside the slice (256 is even: same for all)
+
+  // ---- per-lane A bases: pixel m = i*32 + pix32(r) of the 8 x 16 tile -> halo pixel (2 ly, lx) of the even columns ----
+  int abase[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = i * 32 + pix32(r);
+    abase[i] = (2 * (m >> 4) * HWP + (m & 15)) * ROWB + h * 16;
+  }
+
+  struct Item { int n, y0, x0, tn; };
+  auto decode = [&](int k) {
+    const int item = lb + k * G;
+    Item it;
+    it.tn = item % p.ntn;
+    const int tm = item / p.ntn;
+    it.n = tm / p.tpi;
+    const int tt = tm - it.n * p.tpi;
+    it.y0 = (tt / p.tpi_x) * TH; it.x0 = (tt % p.tpi_x) * TW;
+    return it;
+  };
+  auto issue = [&](const Item& it, int c0, u32x4 (&v)[PPT]) {
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+      v[u] = u32x4{0u, 0u, 0u, 0u};
+      if (pl[u] >= 0) {
+        const int sy = 2 * it.y0 - 1 + (pyx[u] >> 8), sx = 2 * it.x0 - 1 + (pyx[u] & 255);
+        if ((unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
+          v[u] = *reinterpret_cast<const u32x4*>(p.src + ((long long)(it.n * p.Hs + sy) * p.Ws + sx) * p.Cs + c0 + half8);
+      }
+    }
+  };
+  auto commit = [&](char* buf, const u32x4 (&v)[PPT]) {
+#pragma unroll
+    for (int u = 0; u < PPT; ++u)
+      if (pl[u] >= 0) *reinterpret_cast<u32x4*>(buf + pl[u]) = v[u];
+  };
+  // weight fragment of (tap t, column tile tn, k-step kb) for this wave's 32 columns
+  const int lane16 = lane * 16;
+  auto wfrag = [&](int t, int tn, int kb) {  // uniform 64-bit base (SGPRs) + the lane's 32-bit offset
+    const char* base = p.wp + (((long long)t * p.N32 + tn * 4 + wid) * p.KB + kb) * 1024;
+    return *reinterpret_cast<const u32x4*>(base + lane16);
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  // Weight-fragment ring: RING fragments (= taps) ahead of the MFMAs.  25 taps per slice and RING = 10 -> the ring
+  // position of tap 0 alternates between 0 and 5 from one slice to the next: the slice body exists in two copies
+  // (OFF = 0 / 5) so that every ring access is a compile-time register.
+  constexpr int RING = 10;
+  u32x4 bf[RING];
+  u32x4 hv[PPT];
+
+  // ---- prologue: slice 0 of the first item ---------------------------------------------------------------------------
+  Item cur = decode(0);
+  issue(cur, 0, hv);
+#pragma unroll
+  for (int t = 0; t < RING; ++t) bf[t] = wfrag(t, cur.tn, 0);
+  commit(smem, hv);
+  __syncthreads();
+
+  int k = 0, c = 0;  // item index in this block's list, slice index
+  auto slice = [&](auto off_c, int s) {
+    constexpr int OFF = decltype(off_c)::value;
+    const bool more = s + 1 < total;
+    const bool last_c = c + 1 == nchunk;
+    Item nxt = cur;
+    int c2 = c + 1;
+    if (last_c) { c2 = 0; if (more) nxt = decode(k + 1); }
+    if (!more) c2 = c;  // final step: re-request the current slice (valid addresses, results unused) -> no branches below
+    issue(nxt, c2 * KC, hv);
+    const char* hbuf = smem + (s & 1) * HB;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+      bf16x8 a[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes(t));
+      constexpr int dummy = 0; (void)dummy;
+      const int slot = (t + OFF) % RING;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)  // transposed product: rows = this wave's 32 output channels, columns = 32 pixels
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[slot]), a[i], acc[i], 0, 0, 0);
+      // the slot is free: request the fragment RING taps ahead (this slice, or the next one)
+      if (t + RING < NTAP) bf[slot] = wfrag(t + RING, cur.tn, c);
+      else bf[slot] = wfrag(t + RING - NTAP, nxt.tn, c2);
+    }
+    commit(smem + ((s + 1) & 1) * HB, hv);
+    __syncthreads();  // slice s consumed by every wave, slice s+1 complete
+
+    if (last_c) {
+      // ---- epilogue of item `cur`: acc[i][e] = channel (e&3) + 8*(e>>2) + 4*h of pixel i*32 + pix32(r) ---------------
+      char* C = smem + (s & 1) * HB;  // the buffer slice s ran out of is idle until the commit of step s+1
+      const int n0 = cur.tn * 128 + wid * 32;
+      float bv[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) bv[e] = p.bias ? p.bias[n0 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 32 + pix32(r);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 w;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float v = acc[i][4 * g + j] + bv[4 * g + j];
+            if constexpr (STATS) sum += v;
+            w[j] = (__bf16)v;
+          }
+          // 16-B piece (wid*4 + g) of the 256-B row, XOR-swizzled by the row so that both the 8-B writes of a lane group
+          // (16 rows, same piece) and the 16-B row reads (same row, 16 pieces) are conflict-free
+          *reinterpret_cast<bf16x4*>(C + row * 256 + (((wid * 4 + g) ^ (row & 15)) << 4) + 8 * h) = w;
+        }
+      }
+      if constexpr (STATS) {
+        const double ws = lg_wave_sum_d((double)sum);
+        if (lane == 0) sred[wid] = ws;
+      }
+      __syncthreads();  // tile complete in LDS (and the four wave sums)
+      const long long obase = ((long long)(cur.n * p.Hm + cur.y0) * p.Wm + cur.x0) * p.N + cur.tn * 128;
+#pragma unroll
+      for (int q8 = 0; q8 < 8; ++q8) {
+        const int piece = tid + q8 * 256, row = piece >> 4, j = piece & 15;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(C + row * 256 + ((j ^ (row & 15)) << 4));
+        *reinterpret_cast<u32x4*>(p.out + obase + ((long long)(row >> 4) * p.Wm + (row & 15)) * p.N + j * 8) = v;
+      }
+      if constexpr (STATS) {
+        constexpr double cnt = 128.0 * 128.0;
+        const double meand = ((sred[0] + sred[1]) + (sred[2] + sred[3])) / cnt;
+        const float mean = (float)meand;
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { const float d = (acc[i][e] + bv[e]) - mean; m2 += d * d; }
+        const double wm2 = lg_wave_sum_d((double)m2);
+        if (lane == 0) sred[4 + wid] = wm2;
+        __syncthreads();
+        if (tid == 0) {
+          const int tin = (cur.y0 / TH) * p.tpi_x + cur.x0 / TW;
+          double* o = p.spart + ((long long)cur.n * p.nparts + tin * p.ntn + cur.tn) * 3;
+          const double df = (double)mean - meand;  // M2 was taken about the float-rounded mean: shift it to the exact one
+          o[0] = cnt; o[1] = meand; o[2] = ((sred[4] + sred[5]) + (sred[6] + sred[7])) - cnt * df * df;
+        }
+      } else {
+        __syncthreads();  // C fully read before the buffer is staged again
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+      ++k;
+    }
+    cur = nxt;
+    c = c2;
+  };
+  for (int s = 0; s < total; s += 2) {
+    slice(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < total) slice(std::integral_constant<int, NTAP % RING>{}, s + 1);
+  }
+}
+
+}  // namespace
+
+// LG_OK: launched.  LG_ERR_UNSUPPORTED: the caller falls back to the halo-tile kernel of conv_halo.hip.
+extern "C" int lg_conv_down3_try(const void* src16, const void* wpack, const float* bias, void* out16, int B, int Hm, int Wm,
+                                 int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, void* stream) {
+  if (nparts_out) *nparts_out = 0;
+  static int off = -1;
+  if (off < 0) off = getenv("LG_NO_DOWN3") ? 1 : 0;  // A/B switch
+  if (off || !src16 || !wpack || !out16) return LG_ERR_UNSUPPORTED;
+  if (Hm % TH || Wm % TW || Cs % KC || N % 128 || B <= 0) return LG_ERR_UNSUPPORTED;
+  D3Params p{};
+  p.src = (const __bf16*)src16; p.wp = (const char*)wpack; p.bias = bias; p.out = (__bf16*)out16;
+  p.B = B; p.Hm = Hm; p.Wm = Wm; p.Hs = 2 * Hm; p.Ws = 2 * Wm; p.Cs = Cs; p.N = N; p.N32 = N / 32; p.KB = Cs / 16;
+  p.tpi_x = Wm / TW; p.tpi = p.tpi_x * (Hm / TH); p.ntn = N / 128;
+  const long long nitems = (long long)B * p.tpi * p.ntn;
+  if (nitems <= 0 || nitems >= (1ll << 30)) return LG_ERR_UNSUPPORTED;
+  p.nitems = (int)nitems; p.nparts = p.tpi * p.ntn;
+  const bool stats = spart && nparts_out && (size_t)B * p.nparts * 3 * sizeof(double) <= spart_bytes;
+  p.spart = stats ? (double*)spart : nullptr;
+  static int nblk = 0;
+  if (!nblk) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t pr;
+      if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+    }
+    nblk = 2 * cus;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_down3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_down3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  }
+  const int grid = p.nitems < nblk ? p.nitems : nblk;
+  hipStream_t st = (hipStream_t)stream;
+  if (stats) hipLaunchKernelGGL(conv_down3_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, st, p);
+  else hipLaunchKernelGGL(conv_down3_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, st, p);
+  LG_CHECK_LAUNCH("lg_conv_down3");
+  if (stats) *nparts_out = p.nparts;
+  return LG_OK;
+}
+
+extern "C" int lg_conv_down3_supported(int B, int Hm, int Wm, int Cs, int N) {
+  return (!getenv("LG_NO_DOWN3") && B > 0 && Hm % TH == 0 && Wm % TW == 0 && Cs % KC == 0 && N % 128 == 0) ? 1 : 0;
+}

@@ -96,7 +96,10 @@ __device__ __forceinline__ void tap_info(int mode, int cls, int t, int& dy, int&
 // four parity classes one after the other out of that image (grid.y == 1): a quarter of the source traffic and no
 // barrier at all inside the (class, chunk, tap) loops.
 template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES, int WAVES_M, int WAVES_N, int MT, int NT, bool W3 = false>
-__global__ __launch_bounds__(256, (W3 ? 3 : 2)) void conv_halo_kernel(const HaloParams p) {
+#ifndef LG_EXP_W3OCC
+#define LG_EXP_W3OCC 3
+#endif
+__global__ __launch_bounds__(256, (W3 ? LG_EXP_W3OCC : 2)) void conv_halo_kernel(const HaloParams p) {
   static_assert(!W3 || halo_w3_ok<T, MODE, KCH, SRC16, RES, WAVES_M, MT, NT>(), "W3: DOWN, 32-channel chunks, bf16 mirror, 128x32 / 64x32 wave tiles");
   static_assert(!SRC16 || (sizeof(T) == 2 && !DBUF), "bf16 source only with bf16 MFMA, single-buffered halo");
   static_assert(!RES || (SRC16 && MODE == MODE_UP), "resident halo: UP mode from the bf16 mirror");
@@ -198,7 +201,11 @@ __global__ __launch_bounds__(256, (W3 ? 3 : 2)) void conv_halo_kernel(const Halo
   constexpr int NB = NT * KCH;  // B fragments (1 KiB each, 16 B per lane) of one tap for this wave's NT column tiles
   // NSETS register sets of B fragments = the prefetch distance in taps; ~96 VGPRs of fragments in flight whatever the
   // tap's size, so that the distance covers the L2 latency also for the short taps of KCH == 2 (8 MFMAs per tap)
+#ifdef LG_EXP_NSETS
+  constexpr int NSETS = (W3 && MODE == MODE_DOWN) ? LG_EXP_NSETS : ((W3 && MODE == MODE_UP) ? 2 : ((MT * NT == 4 && NB == 4) ? 6 : 3));
+#else
   constexpr int NSETS = (W3 && MODE == MODE_UP) ? 2 : ((MT * NT == 4 && NB == 4) ? 6 : 3);  // deeper only where registers allow
+#endif
   u32x4 fb[NSETS][NB];
 
   int nit = nchunk * ntaps;  // flat (chunk, tap) iteration space

@@ -11,6 +11,8 @@ LAYERS = [  # name, kind, Hs, cb, cs
     ("convT4 fwd 64->128", "up", 64, 32, 64), ("conv2 fwd 64->32", "down", 32, 64, 128), ("conv3 fwd 32->16", "down", 16, 128, 256),
     ("conv4 fwd 16->8", "down", 8, 256, 384), ("final s1t 128", "s1t", 128, 3, 32), ("conv1 dgrad 64->128", "up", 64, 3, 64),
     ("wgrad 16/32 (128,256)", "wgrad", 16, 128, 256), ("wgrad 64/128 (32,64)", "wgrad", 64, 32, 64),
+    ("convT4 dgrad 128->64", "ddown", 64, 32, 64), ("convT3 dgrad 64->32", "ddown", 32, 64, 128), ("convT2 dgrad 32->16", "ddown", 16, 128, 256),
+    ("conv2 dgrad 32->64", "dup", 32, 64, 128), ("conv3 dgrad 16->32", "dup", 16, 128, 256), ("conv4 dgrad 8->16", "dup", 8, 256, 384),
 ]
 M16 = os.environ.get("LG_M16", "1") == "1" and dt == 1  # production bf16 path: sources read from their bf16 mirrors
 gm, bt = torch.ones(1, device="cuda"), torch.zeros(1, device="cuda")
@@ -28,16 +30,25 @@ for name, kind, Hs, cb, cs in LAYERS:
         fn = (lambda: ops.convT_s2_fwd(small, pack, bias_b, cb, dt, out=out)) if cb != 3 else (lambda: ops.conv2d_s2_dgrad(small, pack, cb, dt, out=out))
         if M16 and cb != 3:
             s16 = small.to(torch.bfloat16)
-            fn = lambda: ops.convT_s2_fwd_stats(small, pack, bias_b, cb, dt, gm, bt, x16=s16)
+            fn = lambda: ops.convT_s2_fwd_stats(None, pack, bias_b, cb, dt, gm, bt, x16=s16, z16=True)
     elif kind == "down":
         out = torch.empty(B, Hs, Hs, cs, device="cuda")
         fn = lambda: ops.conv2d_s2_fwd(big, pack, bias_s, cs, dt, out=out)
         if M16:
             b16 = big.to(torch.bfloat16)
-            fn = lambda: ops.conv2d_s2_fwd_stats(big, pack, bias_s, cs, dt, gm, bt, x16=b16)
+            fn = lambda: ops.conv2d_s2_fwd_stats(None, pack, bias_s, cs, dt, gm, bt, x16=b16, z16=True)
+    elif kind == "ddown":  # data gradient of a transposed conv (DOWN form): dz [B,2Hs,2Hs,cb] bf16 -> g [B,Hs,Hs,cs] bf16
+        d16 = big.to(torch.bfloat16)
+        fn = lambda: ops.convT_s2_dgrad(None, pack, cs, dt, dy16=d16, out_bf16=True)
+    elif kind == "dup":    # data gradient of a conv (UP form): dz [B,Hs,Hs,cs] bf16 -> g [B,2Hs,2Hs,cb] bf16
+        d16 = small.to(torch.bfloat16)
+        fn = lambda: ops.conv2d_s2_dgrad(None, pack, cb, dt, dy16=d16, out_bf16=True)
     elif kind == "s1t":
         out = torch.empty(B, Hs, Hs, cb, device="cuda")
         fn = lambda: ops.convT_s1_tanh_fwd(small, pack, bias_b, cb, dt, out=out)
+        if M16:
+            s16 = small.to(torch.bfloat16)
+            fn = lambda: ops.convT_s1_tanh_fwd(None, pack, bias_b, cb, dt, out=out, x16=s16)
     else:
         dw = torch.empty(5, 5, cb, cs, device="cuda")
         fn = lambda: ops.conv2d_s2_wgrad(big, small, dw, False, dt)
