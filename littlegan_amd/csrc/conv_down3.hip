@@ -37,7 +37,12 @@ constexpr int PPT = (NPIECE + 255) / 256;      // pieces per thread (6)
 constexpr int KC = 16;                         // channels per slice = one MFMA k-step
 constexpr int NTAP = 25;
 constexpr int SRED_OFF = 2 * HB;               // 16 doubles of reduction scratch behind the two buffers
-constexpr int LDS_BYTES = 2 * HB + 256;
+constexpr int SBIAS_OFF = 2 * HB + 256;        // 128 floats: bias of the block's current column tile
+constexpr int LDS_BYTES = 2 * HB + 256 + 512;
+#ifndef LG_D3_DBG
+#define LG_D3_DBG 0   // compile-time ablation bits (timing only, results wrong): 1 no MFMA, 2 no fragment loads, 4 no halo staging, 8 no epilogue
+#endif
+constexpr int DBG = LG_D3_DBG;
 
 struct D3Params {
   const __bf16* src;   // [B][Hs][Ws][Cs] bf16
@@ -47,6 +52,8 @@ struct D3Params {
   double* spart;       // [B][nparts][3] or null
   int B, Hs, Ws, Cs, Hm, Wm, N, N32, KB;
   int tpi_x, tpi, ntn, nitems, nparts;
+  int stagger;         // start delay of the odd-slot block in ~1024-cycle units
+  unsigned long long* stamps;  // diagnostic build only (LG_D3_STAMPS): [block][64] s_memtime stamps of wave 0
 };
 
 __device__ __forceinline__ int pix32(int r) {  // MFMA row -> tile pixel inside its 32-pixel group (see conv_halo.hip)
@@ -123,10 +130,13 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
       if (pl[u] >= 0) *reinterpret_cast<u32x4*>(buf + pl[u]) = v[u];
   };
   // weight fragment of (tap t, column tile tn, k-step kb) for this wave's 32 columns
-  const int lane16 = lane * 16;
-  auto wfrag = [&](int t, int tn, int kb) {  // uniform 64-bit base (SGPRs) + the lane's 32-bit offset
-    const char* base = p.wp + (((long long)t * p.N32 + tn * 4 + wid) * p.KB + kb) * 1024;
-    return *reinterpret_cast<const u32x4*>(base + lane16);
+  const unsigned lane16 = lane * 16;
+  const unsigned wstride = (unsigned)p.N32 * (unsigned)p.KB * 1024u;  // bytes from one tap's fragments to the next tap's
+  auto wbase = [&](int tn, int kb) {  // uniform 64-bit base (SGPRs) of (column tile, k-step); taps are wstride apart
+    return p.wp + ((long long)(tn * 4 + wid) * p.KB + kb) * 1024;
+  };
+  auto wfrag = [&](const char* base, int t) {  // SGPR base + 32-bit lane offset: no 64-bit arithmetic in the tap loop
+    return *reinterpret_cast<const u32x4*>((base + (unsigned long long)t * wstride) + lane16);  // scalar add, lane offset
   };
 
   f32x16 acc[4];
@@ -145,11 +155,33 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   Item cur = decode(0);
   issue(cur, 0, hv);
 #pragma unroll
-  for (int t = 0; t < RING; ++t) bf[t] = wfrag(t, cur.tn, 0);
+  for (int t = 0; t < RING; ++t) bf[t] = wfrag(wbase(cur.tn, 0), t);
   commit(smem, hv);
   __syncthreads();
 
+#ifdef LG_D3_STAMPS
+  int nst = 0;
+#define D3_STAMP() do { if (p.stamps && wid == 0 && nst < 64) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) p.stamps[(long long)blockIdx.x * 64 + nst] = t_; ++nst; } } while (0)
+#else
+#define D3_STAMP() do {} while (0)
+#endif
+  // bias of this wave's 32 channels in accumulator order (reloaded only when the column tile changes) and the shift of
+  // the one-pass moments
+  float* sbias = reinterpret_cast<float*>(smem + SBIAS_OFF);
+  auto load_bias = [&](int tn) {  // (a barrier lies between this and the next epilogue that reads it)
+    if (tid < 128) sbias[tid] = p.bias ? p.bias[tn * 128 + tid] : 0.f;
+  };
+  load_bias(cur.tn);
+  {  // Two blocks share a CU (one wave of each per SIMD) and run the same periodic program: started together they stay
+     // in lockstep and meet at the matrix pipe, then idle it together in their epilogues.  The block whose waves sit in
+     // the odd wave slot starts about one epilogue late, so that one block's epilogue / barrier falls into the other's
+     // tap phase (MI355X_MICROARCH, two waves per SIMD, item 9).  Speed only; bounded.
+    // (the dispatcher deals one block to every CU before any CU gets its second: the late half = the upper half of the grid)
+    if (p.stagger && (int)blockIdx.x >= (G + 1) / 2)
+      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);  // ~1024 cycles each
+  }
   int k = 0, c = 0;  // item index in this block's list, slice index
+  D3_STAMP();
   auto slice = [&](auto off_c, int s) {
     constexpr int OFF = decltype(off_c)::value;
     const bool more = s + 1 < total;
@@ -158,33 +190,53 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
     int c2 = c + 1;
     if (last_c) { c2 = 0; if (more) nxt = decode(k + 1); }
     if (!more) c2 = c;  // final step: re-request the current slice (valid addresses, results unused) -> no branches below
-    issue(nxt, c2 * KC, hv);
+    if constexpr (!(DBG & 4)) issue(nxt, c2 * KC, hv);
     const char* hbuf = smem + (s & 1) * HB;
+    const char* wcur = wbase(cur.tn, c);
+    const char* wnxt = wbase(nxt.tn, c2);
+    // The order below is PINNED (sched_barrier): left alone, hipcc sinks every fragment load down to its use and
+    // serialises each MFMA behind its own LDS read (measured in the .s: "ds_read; s_waitcnt lgkmcnt(0); v_mfma" per
+    // MFMA, "global_load; s_waitcnt vmcnt(0)" per tap).  Per tap: the A fragments of tap t+1 are requested, then the 4
+    // MFMAs of tap t issue, then the ring slot they freed is refilled RING taps ahead.
+    bf16x8 a[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes(0));
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) {
-      bf16x8 a[4];
+      if (t + 1 < NTAP) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes(t));
-      constexpr int dummy = 0; (void)dummy;
+        for (int i = 0; i < 4; ++i) a[(t + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes(t + 1 < NTAP ? t + 1 : 0));
+      }
+      __builtin_amdgcn_sched_barrier(0);
       const int slot = (t + OFF) % RING;
 #pragma unroll
       for (int i = 0; i < 4; ++i)  // transposed product: rows = this wave's 32 output channels, columns = 32 pixels
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[slot]), a[i], acc[i], 0, 0, 0);
+        if constexpr (!(DBG & 1)) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[slot]), a[t & 1][i], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
       // the slot is free: request the fragment RING taps ahead (this slice, or the next one)
-      if (t + RING < NTAP) bf[slot] = wfrag(t + RING, cur.tn, c);
-      else bf[slot] = wfrag(t + RING - NTAP, nxt.tn, c2);
+      if constexpr (!(DBG & 2)) {
+        if (t + RING < NTAP) bf[slot] = wfrag(wcur, t + RING);
+        else bf[slot] = wfrag(wnxt, t + RING - NTAP);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    D3_STAMP();   // taps done
     commit(smem + ((s + 1) & 1) * HB, hv);
     __syncthreads();  // slice s consumed by every wave, slice s+1 complete
+    D3_STAMP();   // barrier passed
 
-    if (last_c) {
+    if (last_c && !(DBG & 8)) {
       // ---- epilogue of item `cur`: acc[i][e] = channel (e&3) + 8*(e>>2) + 4*h of pixel i*32 + pix32(r) ---------------
       char* C = smem + (s & 1) * HB;  // the buffer slice s ran out of is idle until the commit of step s+1
-      const int n0 = cur.tn * 128 + wid * 32;
-      float bv[16];
+      // moments in ONE pass: sums of d = v - shift and d^2 (shift = the block's first bias value, near the tile mean for
+      // zero-mean kernels), fp32 per lane over its 64 values, fp64 from there on:  M2 = S2 - S1^2 / count
+      const float shift = STATS ? sbias[0] : 0.f;
+      const f32x2 shift2 = {shift, shift};
+      f32x2 s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
+      f32x4 bq[4];  // bias of channels 8g + 4h + {0..3} of this wave's 32
 #pragma unroll
-      for (int e = 0; e < 16; ++e) bv[e] = p.bias ? p.bias[n0 + (e & 3) + 8 * (e >> 2) + 4 * h] : 0.f;
-      float sum = 0.f;
+      for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(sbias + wid * 32 + 8 * g + 4 * h);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = i * 32 + pix32(r);
@@ -192,10 +244,14 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
         for (int g = 0; g < 4; ++g) {
           bf16x4 w;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float v = acc[i][4 * g + j] + bv[4 * g + j];
-            if constexpr (STATS) sum += v;
-            w[j] = (__bf16)v;
+          for (int jj = 0; jj < 2; ++jj) {  // two channels at a time: v_pk_add_f32 / v_pk_fma_f32 halve the VALU count
+            const f32x2 v = f32x2{acc[i][4 * g + 2 * jj], acc[i][4 * g + 2 * jj + 1]} + f32x2{bq[g][2 * jj], bq[g][2 * jj + 1]};
+            if constexpr (STATS) {
+              const f32x2 d = v - shift2;
+              s1v += d;
+              s2v = __builtin_elementwise_fma(d, d, s2v);
+            }
+            w[2 * jj] = (__bf16)v[0]; w[2 * jj + 1] = (__bf16)v[1];
           }
           // 16-B piece (wid*4 + g) of the 256-B row, XOR-swizzled by the row so that both the 8-B writes of a lane group
           // (16 rows, same piece) and the 16-B row reads (same row, 16 pieces) are conflict-free
@@ -203,10 +259,10 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
         }
       }
       if constexpr (STATS) {
-        const double ws = lg_wave_sum_d((double)sum);
-        if (lane == 0) sred[wid] = ws;
+        const double w1 = lg_wave_sum_d((double)s1v[0] + (double)s1v[1]), w2 = lg_wave_sum_d((double)s2v[0] + (double)s2v[1]);
+        if (lane == 0) { sred[(k & 1) * 8 + wid] = w1; sred[(k & 1) * 8 + 4 + wid] = w2; }
       }
-      __syncthreads();  // tile complete in LDS (and the four wave sums)
+      __syncthreads();  // tile complete in LDS (and the wave sums)
       const long long obase = ((long long)(cur.n * p.Hm + cur.y0) * p.Wm + cur.x0) * p.N + cur.tn * 128;
 #pragma unroll
       for (int q8 = 0; q8 < 8; ++q8) {
@@ -215,31 +271,24 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
         *reinterpret_cast<u32x4*>(p.out + obase + ((long long)(row >> 4) * p.Wm + (row & 15)) * p.N + j * 8) = v;
       }
       if constexpr (STATS) {
-        constexpr double cnt = 128.0 * 128.0;
-        const double meand = ((sred[0] + sred[1]) + (sred[2] + sred[3])) / cnt;
-        const float mean = (float)meand;
-        float m2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) { const float d = (acc[i][e] + bv[e]) - mean; m2 += d * d; }
-        const double wm2 = lg_wave_sum_d((double)m2);
-        if (lane == 0) sred[4 + wid] = wm2;
-        __syncthreads();
         if (tid == 0) {
+          constexpr double cnt = 128.0 * 128.0;
+          const double* q = sred + (k & 1) * 8;
+          const double S1 = (q[0] + q[1]) + (q[2] + q[3]), S2 = (q[4] + q[5]) + (q[6] + q[7]);
+          const double md = S1 / cnt;
           const int tin = (cur.y0 / TH) * p.tpi_x + cur.x0 / TW;
           double* o = p.spart + ((long long)cur.n * p.nparts + tin * p.ntn + cur.tn) * 3;
-          const double df = (double)mean - meand;  // M2 was taken about the float-rounded mean: shift it to the exact one
-          o[0] = cnt; o[1] = meand; o[2] = ((sred[4] + sred[5]) + (sred[6] + sred[7])) - cnt * df * df;
+          o[0] = cnt; o[1] = (double)shift + md; o[2] = S2 - cnt * md * md;
         }
-      } else {
-        __syncthreads();  // C fully read before the buffer is staged again
       }
+      __syncthreads();  // C fully read before the buffer is staged again (sred alternates between two sets of slots)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+      if (more && nxt.tn != cur.tn) load_bias(nxt.tn);
       ++k;
+      D3_STAMP();  // epilogue done
     }
     cur = nxt;
     c = c2;
@@ -267,6 +316,10 @@ extern "C" int lg_conv_down3_try(const void* src16, const void* wpack, const flo
   const long long nitems = (long long)B * p.tpi * p.ntn;
   if (nitems <= 0 || nitems >= (1ll << 30)) return LG_ERR_UNSUPPORTED;
   p.nitems = (int)nitems; p.nparts = p.tpi * p.ntn;
+  { static int stg = -1; if (stg < 0) { const char* e = getenv("LG_D3_STAGGER"); stg = e ? atoi(e) : 6; } p.stagger = stg; }
+#ifdef LG_D3_STAMPS
+  { const char* e = getenv("LG_D3_STAMPBUF"); p.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
   const bool stats = spart && nparts_out && (size_t)B * p.nparts * 3 * sizeof(double) <= spart_bytes;
   p.spart = stats ? (double*)spart : nullptr;
   static int nblk = 0;
