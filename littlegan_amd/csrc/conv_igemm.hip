@@ -352,6 +352,8 @@ extern "C" int lg_npad(int n) {
 extern "C" int lg_conv_igemm_ex(int mode, int dtype, const float* src, const void* src16, const void* wpack,
                                 const float* bias, float* out, void* out16, int B, int Hm, int Wm, int Cs, int N, int act,
                                 int pstride, int ppad, void* spart, size_t spart_bytes, int* nparts_out, void* stream);
+extern "C" int lg_conv_up3_try(const void* src16, const void* wpack_up, const float* bias, void* out16, int B, int Hm, int Wm,
+                               int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, void* stream);
 extern "C" int lg_conv_down3_try(const void* src16, const void* wpack, const float* bias, void* out16, int B, int Hm, int Wm,
                                  int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, void* stream);
 
@@ -382,6 +384,11 @@ extern "C" int lg_conv_igemm_ex(int mode, int dtype, const float* src, const voi
   if (mode == MODE_DOWN && dtype == LG_DT_BF16 && src16 && out16 && act == 0 && halo_enabled()) {
     // software-pipelined persistent kernel (conv_down3.hip) for the bf16 activation path where its tiling applies
     rc = lg_conv_down3_try(src16, wpack, bias, out16, B, Hm, Wm, Cs, N, spart, spart_bytes, nparts_out, stream);
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+  }
+  if (mode == MODE_UP && dtype == LG_DT_BF16 && src16 && out16 && act == 0 && halo_enabled()) {
+    // resident-halo persistent kernel with the four parity classes on concurrent waves (conv_up3.hip): small-N layers
+    rc = lg_conv_up3_try(src16, wpack, bias, out16, B, Hm, Wm, Cs, N, spart, spart_bytes, nparts_out, stream);
     if (rc != LG_ERR_UNSUPPORTED) return rc;
   }
   if (mode != MODE_PATCH && halo_enabled()) {  // LDS halo-tile kernel where the tiling covers the shape

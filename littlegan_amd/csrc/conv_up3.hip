@@ -1,0 +1,355 @@
+// Software-pipelined stride-2 "up" contraction for gfx950 (bf16 operands, fp32 accumulation), small-N layers:
+//   out[n][2y+py][2x+px][co] = bias[co] + sum_{taps (ky,kx) of parity class (py,px)} sum_ci src[n][y+dy][x+dx][ci] W[ky][kx][co][ci]
+// = Conv2DTranspose(f, 5, 2, same) forward (model.py:39-40) and the data gradient of Conv2D(f, 5, 2, same) (model.py:15),
+// for the layers with few output channels and a source that fits LDS whole:
+//   CS = 128, N = 64 : convT3 forward, conv2 data gradient        CS = 64, N = 32 : convT4 forward
+// (the generator's 32..64-channel levels: the bulk of the transposed-conv stack's time in conv_halo.hip, where their
+//  blocks of 128 output-class pixels re-fetch the whole weight tensor per 32 / 64 pixel rows and spend most of their life
+//  in prologue and epilogue).
+//
+// One workgroup of 8 waves per CU walks a list of 8 x 16 source-pixel tiles (NT tiles at a time):
+//   * the source halo of a tile (10 x 18 pixels, ALL channels) is resident in LDS; the next tile's halo is in flight
+//     global -> registers while this one computes and is written behind the last MFMA: two barriers per tile, none inside;
+//   * the FOUR parity classes of a tile run CONCURRENTLY on different waves — a wave owns (column half | tile, class) and
+//     all 128 pixels (4 MFMA row tiles), so every weight fragment is fetched by exactly one wave and used for 4 MFMAs;
+//     the classes have 9 / 6 / 6 / 4 taps, and waves w and w + 4 share a SIMD: class (3 | 0) and (1 | 2) pairs balance it;
+//   * weight fragments (fragment order of pack.hip) stream global -> registers through an 8-deep ring; they do not
+//     depend on the tile, so the stream never drains; every LDS address of a tap is the lane's base + a compile-time offset;
+//   * the product is formed transposed (channels on accumulator rows, pixels on lanes) and leaves the registers through a
+//     WHOLE-OUTPUT-TILE staging area in LDS (16 x 32 output pixels x N channels): the four classes interleave there and
+//     the tile reaches HBM as contiguous rows of 32 pixels x N channels, 16 B per lane;
+//   * the InstanceNormalization moments of the tile come out of the same registers (one pass about a shift).
+#include <stdlib.h>
+#include <type_traits>
+#include "lg_common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16, HHT = TH + 2, HWT = TW + 2, NPX = HHT * HWT;  // 10 x 18 = 180 halo pixels
+constexpr int RING = 8;
+
+template <int CS, int N> struct Cfg {
+  static constexpr int WN = N / 32;               // column waves per tile (2 | 1)
+  static constexpr int NT = 2 / WN;               // tiles per workgroup step (1 | 2): 8 waves = NT * WN * 4 classes
+  static constexpr int PITCH = CS * 2 + 16;       // halo pixel pitch (bytes): consecutive pixels shift by one 16-B slot
+  static constexpr int HB = NPX * PITCH;          // halo bytes per tile
+  static constexpr int OPX = 4 * TH * TW;         // 512 output pixels per tile
+  static constexpr int CROW = N * 2;              // output pixel row in the staging area (bytes): 128 | 64
+  static constexpr int CB = OPX * CROW;           // staging bytes per tile
+  static constexpr int KB = CS / 16;              // k-steps
+  static constexpr int C_OFF = NT * HB;
+  static constexpr int SRED_OFF = C_OFF + NT * CB;
+  static constexpr int SBIAS_OFF = SRED_OFF + 2 * 8 * 2 * 8;  // [2 parities][8 waves][2] doubles
+  static constexpr int LDS = SBIAS_OFF + N * 4;
+  static constexpr int PIECES = NT * NPX * (CS * 2 / 16);       // 16-B halo pieces per step
+  static constexpr int PPT = (PIECES + 511) / 512;
+};
+
+struct U3Params {
+  const __bf16* src;   // [B][Hs][Ws][CS]
+  const char* wp;      // "up" pack [25][N/32][CS/16][64][16 B]
+  const float* bias;   // [N] or null
+  __bf16* out;         // [B][2Hs][2Ws][N]
+  double* spart;       // [B][tpi][3] or null
+  int B, Hs, Ws, tpi_x, tpi, nitems;
+};
+
+__device__ __forceinline__ int pix32(int r) {
+  const int q = r >> 2, lo = r & 3;
+  const int odd = (q ^ (q >> 1) ^ (q >> 2)) & 1;
+  const int rank = odd ? ((q == 1) ? 0 : (q == 2) ? 1 : (q == 4) ? 2 : 3) : ((q == 0) ? 0 : (q == 3) ? 1 : (q == 5) ? 2 : 3);
+  return odd * 16 + rank * 4 + lo;
+}
+
+// class = 2*py + px; taps a < nky(py), b < nkx(px):  ky = py ? 2a : 2a+1, dy = (py + 1 - ky) / 2  (same in x)
+constexpr int nk(int p) { return p ? 3 : 2; }
+constexpr int ntaps_of(int cls) { return nk(cls >> 1) * nk(cls & 1); }
+constexpr int tap_k(int p, int a) { return p ? 2 * a : 2 * a + 1; }
+constexpr int tap_d(int p, int a) { return (p + 1 - tap_k(p, a)) / 2; }
+
+template <int CS, int N, bool STATS>
+__global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
+  using C = Cfg<CS, N>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* sred = reinterpret_cast<double*>(smem + C::SRED_OFF);
+  float* sbias = reinterpret_cast<float*>(smem + C::SBIAS_OFF);
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // wave roles.  N = 64: (column half, class slot); N = 32: (tile, class slot).  Waves w and w+4 share a SIMD: slots
+  // pair the 9-tap class with the 4-tap one and the two 6-tap ones.
+  const int wn = C::WN == 2 ? (wid & 1) : 0;
+  const int tsel = C::WN == 2 ? 0 : (wid >> 2);                      // which of the NT tiles
+  const int slot = C::WN == 2 ? (wid >> 1) : (wid & 3);
+  const int cls = C::WN == 2 ? (slot == 0 ? 3 : slot == 1 ? 1 : slot == 2 ? 0 : 2)
+                             : (tsel == 0 ? (slot == 0 ? 3 : slot == 1 ? 1 : slot == 2 ? 2 : 0) : (slot == 0 ? 0 : slot == 1 ? 2 : slot == 2 ? 1 : 3));
+  const int G = gridDim.x;
+  const int lb = lg_xcd_remap(blockIdx.x, G);
+  const int nsteps_all = (p.nitems + C::NT - 1) / C::NT;       // steps (NT tiles each) over the whole problem
+  const int nmine = (nsteps_all - lb + G - 1) / G;
+
+  if (tid < N) sbias[tid] = p.bias ? p.bias[tid] : 0.f;
+
+  // ---- halo pieces of this thread (same positions every step) -----------------------------------------------------------
+  constexpr int PPR = CS * 2 / 16;  // 16-B pieces per halo pixel
+  int pl[C::PPT], pyx[C::PPT];
+#pragma unroll
+  for (int u = 0; u < C::PPT; ++u) {
+    const int q = tid + u * 512;
+    pl[u] = -1; pyx[u] = 0;
+    if (q < C::PIECES) {
+      const int t = q / (NPX * PPR), rem = q - t * (NPX * PPR);
+      const int px = rem / PPR, pc = rem - px * PPR;
+      const int hy = px / HWT, hx = px - hy * HWT;
+      pl[u] = t * C::HB + px * C::PITCH + pc * 16;
+      pyx[u] = (t << 20) | (pc << 12) | (hy << 6) | hx;
+    }
+  }
+  auto tile_of = [&](int step, int t, int& n, int& y0, int& x0) {  // false: no such tile (odd tail)
+    const int item = (lb + step * G) * C::NT + t;
+    if (item >= p.nitems) { n = 0; y0 = 0; x0 = 0; return false; }
+    n = item / p.tpi;
+    const int tt = item - n * p.tpi;
+    y0 = (tt / p.tpi_x) * TH; x0 = (tt % p.tpi_x) * TW;
+    return true;
+  };
+  auto issue = [&](int step, u32x4 (&v)[C::PPT]) {
+    int n[C::NT], y0[C::NT], x0[C::NT];
+    bool ok[C::NT];
+#pragma unroll
+    for (int t = 0; t < C::NT; ++t) ok[t] = tile_of(step, t, n[t], y0[t], x0[t]);
+#pragma unroll
+    for (int u = 0; u < C::PPT; ++u) {
+      v[u] = u32x4{0u, 0u, 0u, 0u};
+      if (pl[u] >= 0) {
+        const bool t1 = C::NT == 2 && (pyx[u] >> 20) != 0;  // selects, not runtime-indexed arrays (those go to scratch)
+        const int ty = t1 ? y0[C::NT - 1] : y0[0], tx = t1 ? x0[C::NT - 1] : x0[0], tn = t1 ? n[C::NT - 1] : n[0];
+        const bool tok = t1 ? ok[C::NT - 1] : ok[0];
+        const int sy = ty - 1 + ((pyx[u] >> 6) & 63), sx = tx - 1 + (pyx[u] & 63);
+        if (tok && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
+          v[u] = *reinterpret_cast<const u32x4*>(p.src + ((long long)(tn * p.Hs + sy) * p.Ws + sx) * CS + ((pyx[u] >> 12) & 255) * 8);
+      }
+    }
+  };
+  auto commit = [&](const u32x4 (&v)[C::PPT]) {
+#pragma unroll
+    for (int u = 0; u < C::PPT; ++u)
+      if (pl[u] >= 0) *reinterpret_cast<u32x4*>(smem + pl[u]) = v[u];
+  };
+
+  // ---- per-lane A bases (pixel m = i*32 + pix32(r) at halo position (ly, lx); taps add (dy+1, dx+1)) -----------------------
+  int abase[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = i * 32 + pix32(r);
+    abase[i] = tsel * C::HB + ((m >> 4) * HWT + (m & 15)) * C::PITCH + h * 16;
+  }
+  const unsigned lane16 = lane * 16;
+  const char* wwave = p.wp + (long long)wn * C::KB * 1024;      // this wave's column tile
+  constexpr unsigned WTAP = (unsigned)(N / 32) * C::KB * 1024u;  // bytes from one tap's fragments to the next tap's
+
+  u32x4 bf[RING];
+  u32x4 hv[C::PPT];
+  f32x16 acc[4];
+
+  // fragment f of class CLS: tap = f / KB, k-step = f % KB
+  const char* wcur = wwave;  // re-materialised (opaque) per tile: keeps the 72 fragment addresses out of loop-invariant VGPRs
+  auto frag_ptr = [&](auto cls_c, int f) {
+    constexpr int CLS = decltype(cls_c)::value;
+    constexpr int PY = CLS >> 1, PX = CLS & 1, NKX = nk(PX);
+    const int t = f / C::KB, kb = f - t * C::KB;
+    const int a = t / NKX, b = t - a * NKX;
+    const int widx = tap_k(PY, a) * 5 + tap_k(PX, b);
+    return (wcur + ((unsigned long long)widx * WTAP + kb * 1024)) + lane16;  // scalar base + constant, 32-bit lane offset
+  };
+
+  // ---- prologue ----------------------------------------------------------------------------------------------------------
+  issue(0, hv);
+  auto prime = [&](auto cls_c) {
+#pragma unroll
+    for (int f = 0; f < RING; ++f) bf[f] = *reinterpret_cast<const u32x4*>(frag_ptr(cls_c, f));
+  };
+  if (cls == 3) prime(std::integral_constant<int, 3>{});
+  else if (cls == 2) prime(std::integral_constant<int, 2>{});
+  else if (cls == 1) prime(std::integral_constant<int, 1>{});
+  else prime(std::integral_constant<int, 0>{});
+  commit(hv);
+  __syncthreads();
+
+  // one class of one tile: F = taps * KB fragments, ring position OFF at entry (F % RING != 0 only for CS = 64, class 3)
+  auto run_class = [&](auto cls_c, auto off_c) {
+    constexpr int CLS = decltype(cls_c)::value, OFF = decltype(off_c)::value;
+    constexpr int PY = CLS >> 1, PX = CLS & 1, NKX = nk(PX), F = ntaps_of(CLS) * C::KB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    wcur = wwave;
+    asm volatile("" : "+s"(wcur));  // opaque to LICM (a scalar pair; the adds below are SALU)
+    bf16x8 a[2][4];
+    auto a_off = [&](int f) {  // compile-time after unrolling
+      const int t = f / C::KB, kb = f - t * C::KB;
+      const int ta = t / NKX, tb = t - ta * NKX;
+      return ((tap_d(PY, ta) + 1) * HWT + tap_d(PX, tb) + 1) * C::PITCH + kb * 32;
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(smem + abase[i] + a_off(0));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      if (f + 1 < F) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[(f + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(smem + abase[i] + a_off(f + 1 < F ? f + 1 : 0));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int dummy = 0; (void)dummy;
+      const int sl = (f + OFF) % RING;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[sl]), a[f & 1][i], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      bf[sl] = *reinterpret_cast<const u32x4*>(frag_ptr(cls_c, (f + RING) % F));  // the stream wraps: same weights every tile
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  int roff = 0;  // ring position at the start of this wave's class (toggles 0 / 4 when F % RING == 4)
+  for (int s = 0; s < nmine; ++s) {
+    const bool more = s + 1 < nmine;
+    if (more) issue(s + 1, hv);
+    int n, y0, x0;
+    const bool live = tile_of(s, tsel, n, y0, x0);  // (N = 32: the second tile of the last step may not exist: computed, not stored)
+
+    if (cls == 3) {
+      if (roff == 0) run_class(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
+      else run_class(std::integral_constant<int, 3>{}, std::integral_constant<int, (RING / 2) % RING>{});
+      roff = (roff + ntaps_of(3) * C::KB) % RING;
+    } else if (cls == 2) run_class(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+    else if (cls == 1) run_class(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    else run_class(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+
+    // ---- this wave's class into the output-tile staging area: acc[i][e] = channel (e&3) + 8*(e>>2) + 4*h of pixel m ----------
+    {
+      char* Cst = smem + C::C_OFF + tsel * C::CB;
+      const int py = cls >> 1, px = cls & 1;
+      const float shift = STATS ? sbias[0] : 0.f;
+      const f32x2 shift2 = {shift, shift};
+      f32x2 s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
+      f32x4 bq[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(sbias + wn * 32 + 8 * g + 4 * h);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = i * 32 + pix32(r);
+        const int o = (2 * (m >> 4) + py) * (2 * TW) + 2 * (m & 15) + px;  // output pixel inside the 16 x 32 tile
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 w;
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const f32x2 v = f32x2{acc[i][4 * g + 2 * jj], acc[i][4 * g + 2 * jj + 1]} + f32x2{bq[g][2 * jj], bq[g][2 * jj + 1]};
+            if constexpr (STATS) {
+              const f32x2 d = v - shift2;
+              s1v += d;
+              s2v = __builtin_elementwise_fma(d, d, s2v);
+            }
+            w[2 * jj] = (__bf16)v[0]; w[2 * jj + 1] = (__bf16)v[1];
+          }
+          // piece (wn*4 + g) of the pixel's row, XOR-swizzled with the pixel pair index (neighbouring lanes are 2 pixels apart)
+          constexpr int PM = C::CROW / 16 - 1;
+          *reinterpret_cast<bf16x4*>(Cst + o * C::CROW + ((((wn * 4 + g) ^ (o >> 1)) & PM) << 4) + 8 * h) = w;
+        }
+      }
+      if constexpr (STATS) {
+        const double w1 = lg_wave_sum_d((double)s1v[0] + (double)s1v[1]), w2 = lg_wave_sum_d((double)s2v[0] + (double)s2v[1]);
+        if (lane == 0) { sred[((s & 1) * 8 + wid) * 2] = w1; sred[((s & 1) * 8 + wid) * 2 + 1] = w2; }
+      }
+    }
+    __syncthreads();  // every class of the tile(s) is staged, every halo read is done
+
+    if (more) commit(hv);
+    // ---- whole output rows out: 16 rows x (32 pixels x N channels) contiguous, 16 B per lane ------------------------------
+    {
+      constexpr int PPO = C::CROW / 16;                 // pieces per output pixel (8 | 4)
+      constexpr int TOT = C::NT * C::OPX * PPO;         // 4096 pieces per step either way
+#pragma unroll
+      for (int q8 = 0; q8 < TOT / 512; ++q8) {
+        const int q = tid + q8 * 512;
+        const int t = q / (C::OPX * PPO), rem = q - t * (C::OPX * PPO);
+        const int o = rem / PPO, j = rem - o * PPO;
+        int tn_, ty0, tx0;
+        const bool tl = tile_of(s, t, tn_, ty0, tx0);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + C::C_OFF + t * C::CB + o * C::CROW + (((j ^ (o >> 1)) & (PPO - 1)) << 4));
+        if (tl)
+          *reinterpret_cast<u32x4*>(p.out + ((long long)(tn_ * 2 * p.Hs + 2 * ty0 + (o >> 5)) * (2 * p.Ws) + 2 * tx0 + (o & 31)) * N + j * 8) = v;
+      }
+    }
+    if constexpr (STATS) {
+      if (tid < C::NT) {  // one record per tile: the 8 / NT waves of that tile
+        int tn_, ty0, tx0;
+        if (tile_of(s, tid, tn_, ty0, tx0)) {
+          double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+          for (int w = 0; w < 8; ++w) {
+            const bool mine = C::WN == 2 ? true : ((w >> 2) == tid);
+            if (mine) { S1 += sred[((s & 1) * 8 + w) * 2]; S2 += sred[((s & 1) * 8 + w) * 2 + 1]; }
+          }
+          constexpr double cnt = (double)(C::OPX * N);
+          const double md = S1 / cnt;
+          const int tin = (ty0 / TH) * p.tpi_x + tx0 / TW;
+          double* o = p.spart + ((long long)tn_ * p.tpi + tin) * 3;
+          o[0] = cnt; o[1] = (double)sbias[0] + md; o[2] = S2 - cnt * md * md;
+        }
+      }
+    }
+    (void)live;
+    __syncthreads();  // next halo complete, staging area free again
+  }
+}
+
+template <int CS, int N>
+int launch_up3(U3Params p, bool stats, hipStream_t st) {
+  using C = Cfg<CS, N>;
+  static int nblk = 0;
+  if (!nblk) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t pr;
+      if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+    }
+    nblk = cus;  // one 8-wave workgroup per CU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, true>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+  }
+  const int nsteps = (p.nitems + C::NT - 1) / C::NT;
+  const int grid = nsteps < nblk ? nsteps : nblk;
+  if (stats) hipLaunchKernelGGL((conv_up3_kernel<CS, N, true>), dim3(grid), dim3(512), C::LDS, st, p);
+  else hipLaunchKernelGGL((conv_up3_kernel<CS, N, false>), dim3(grid), dim3(512), C::LDS, st, p);
+  return LG_OK;
+}
+
+}  // namespace
+
+extern "C" int lg_conv_up3_supported(int B, int Hm, int Wm, int Cs, int N) {
+  return (!getenv("LG_NO_UP3") && B > 0 && Hm % TH == 0 && Wm % TW == 0 && ((Cs == 128 && N == 64) || (Cs == 64 && N == 32))) ? 1 : 0;
+}
+
+// LG_OK: launched.  LG_ERR_UNSUPPORTED: the caller falls back to conv_halo.hip.  *nparts_out = records per sample (tiles).
+extern "C" int lg_conv_up3_try(const void* src16, const void* wpack_up, const float* bias, void* out16, int B, int Hm, int Wm,
+                               int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, void* stream) {
+  if (nparts_out) *nparts_out = 0;
+  if (!src16 || !wpack_up || !out16 || !lg_conv_up3_supported(B, Hm, Wm, Cs, N)) return LG_ERR_UNSUPPORTED;
+  U3Params p{};
+  p.src = (const __bf16*)src16; p.wp = (const char*)wpack_up; p.bias = bias; p.out = (__bf16*)out16;
+  p.B = B; p.Hs = Hm; p.Ws = Wm; p.tpi_x = Wm / TW; p.tpi = p.tpi_x * (Hm / TH);
+  const long long nitems = (long long)B * p.tpi;
+  if (nitems <= 0 || nitems >= (1ll << 30)) return LG_ERR_UNSUPPORTED;
+  p.nitems = (int)nitems;
+  const bool stats = spart && nparts_out && (size_t)B * p.tpi * 3 * sizeof(double) <= spart_bytes;
+  p.spart = stats ? (double*)spart : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (Cs == 128) launch_up3<128, 64>(p, stats, st);
+  else launch_up3<64, 32>(p, stats, st);
+  LG_CHECK_LAUNCH("lg_conv_up3");
+  if (stats) *nparts_out = p.tpi;
+  return LG_OK;
+}
