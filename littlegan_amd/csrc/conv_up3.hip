@@ -39,7 +39,7 @@ template <int CS, int N> struct Cfg {
   static constexpr int KB = CS / 16;              // k-steps
   static constexpr int C_OFF = NT * HB;
   static constexpr int SRED_OFF = C_OFF + NT * CB;
-  static constexpr int SBIAS_OFF = SRED_OFF + 2 * 8 * 2 * 8;  // [2 parities][8 waves][2] doubles
+  static constexpr int SBIAS_OFF = SRED_OFF + 512 * 8;        // per-thread {sum d, sum d^2} floats of the current step
   static constexpr int LDS = SBIAS_OFF + N * 4;
   static constexpr int PIECES = NT * NPX * (CS * 2 / 16);       // 16-B halo pieces per step
   static constexpr int PPT = (PIECES + 511) / 512;
@@ -52,6 +52,7 @@ struct U3Params {
   __bf16* out;         // [B][2Hs][2Ws][N]
   double* spart;       // [B][tpi][3] or null
   int B, Hs, Ws, tpi_x, tpi, nitems;
+  unsigned long long* stamps;  // diagnostic build (LG_U3_STAMPS): [block][8 waves][32]
 };
 
 __device__ __forceinline__ int pix32(int r) {
@@ -71,7 +72,7 @@ template <int CS, int N, bool STATS>
 __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
   using C = Cfg<CS, N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* sred = reinterpret_cast<double*>(smem + C::SRED_OFF);
+  f32x2* sstat = reinterpret_cast<f32x2*>(smem + C::SRED_OFF);
   float* sbias = reinterpret_cast<float*>(smem + C::SBIAS_OFF);
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -152,14 +153,17 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
   f32x16 acc[4];
 
   // fragment f of class CLS: tap = f / KB, k-step = f % KB
-  const char* wcur = wwave;  // re-materialised (opaque) per tile: keeps the 72 fragment addresses out of loop-invariant VGPRs
+  // (an opaque zero added per tile keeps the 72 fragment addresses out of loop-invariant VGPRs; the POINTER itself must
+  //  not pass through the asm: it would come back as a generic pointer and every fragment load would become a flat_load,
+  //  which counts on vmcnt AND lgkmcnt and forces "s_waitcnt vmcnt(0) lgkmcnt(0)" before each MFMA group)
+  unsigned long long wzero = 0;
   auto frag_ptr = [&](auto cls_c, int f) {
     constexpr int CLS = decltype(cls_c)::value;
     constexpr int PY = CLS >> 1, PX = CLS & 1, NKX = nk(PX);
     const int t = f / C::KB, kb = f - t * C::KB;
     const int a = t / NKX, b = t - a * NKX;
     const int widx = tap_k(PY, a) * 5 + tap_k(PX, b);
-    return (wcur + ((unsigned long long)widx * WTAP + kb * 1024)) + lane16;  // scalar base + constant, 32-bit lane offset
+    return (wwave + (wzero + ((unsigned long long)widx * WTAP + kb * 1024))) + lane16;  // scalar base + constant, 32-bit lane offset
   };
 
   // ---- prologue ----------------------------------------------------------------------------------------------------------
@@ -183,8 +187,8 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-    wcur = wwave;
-    asm volatile("" : "+s"(wcur));  // opaque to LICM (a scalar pair; the adds below are SALU)
+    wzero = 0;
+    asm volatile("" : "+s"(wzero));  // opaque to LICM (a scalar pair; the adds below are SALU)
     bf16x8 a[2][4];
     auto a_off = [&](int f) {  // compile-time after unrolling
       const int t = f / C::KB, kb = f - t * C::KB;
@@ -212,11 +216,18 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
     }
   };
 
+#ifdef LG_U3_STAMPS
+  int nst = 0;
+#define U3_STAMP() do { if (p.stamps && nst < 32) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) p.stamps[((long long)blockIdx.x * 8 + wid) * 32 + nst] = t_; ++nst; } } while (0)
+#else
+#define U3_STAMP() do {} while (0)
+#endif
   int roff = 0;  // ring position at the start of this wave's class (toggles 0 / 4 when F % RING == 4)
   for (int s = 0; s < nmine; ++s) {
     const bool more = s + 1 < nmine;
     if (more) issue(s + 1, hv);
     int n, y0, x0;
+    U3_STAMP();  // item start
     const bool live = tile_of(s, tsel, n, y0, x0);  // (N = 32: the second tile of the last step may not exist: computed, not stored)
 
     if (cls == 3) {
@@ -227,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
     else if (cls == 1) run_class(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
     else run_class(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
 
+    U3_STAMP();  // class computed
     // ---- this wave's class into the output-tile staging area: acc[i][e] = channel (e&3) + 8*(e>>2) + 4*h of pixel m ----------
     {
       char* Cst = smem + C::C_OFF + tsel * C::CB;
@@ -259,14 +271,17 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
           *reinterpret_cast<bf16x4*>(Cst + o * C::CROW + ((((wn * 4 + g) ^ (o >> 1)) & PM) << 4) + 8 * h) = w;
         }
       }
-      if constexpr (STATS) {
-        const double w1 = lg_wave_sum_d((double)s1v[0] + (double)s1v[1]), w2 = lg_wave_sum_d((double)s2v[0] + (double)s2v[1]);
-        if (lane == 0) { sred[((s & 1) * 8 + wid) * 2] = w1; sred[((s & 1) * 8 + wid) * 2 + 1] = w2; }
-      }
+      if constexpr (STATS) sstat[tid] = f32x2{s1v[0] + s1v[1], s2v[0] + s2v[1]};  // reduced by ONE wave per tile behind the barrier
     }
+    U3_STAMP();  // staged
     __syncthreads();  // every class of the tile(s) is staged, every halo read is done
+    U3_STAMP();  // barrier 1 passed
 
     if (more) commit(hv);
+    int tns[C::NT], ty0s[C::NT], tx0s[C::NT];
+    bool tlive[C::NT];
+#pragma unroll
+    for (int t = 0; t < C::NT; ++t) tlive[t] = tile_of(s, t, tns[t], ty0s[t], tx0s[t]);
     // ---- whole output rows out: 16 rows x (32 pixels x N channels) contiguous, 16 B per lane ------------------------------
     {
       constexpr int PPO = C::CROW / 16;                 // pieces per output pixel (8 | 4)
@@ -276,32 +291,40 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
         const int q = tid + q8 * 512;
         const int t = q / (C::OPX * PPO), rem = q - t * (C::OPX * PPO);
         const int o = rem / PPO, j = rem - o * PPO;
-        int tn_, ty0, tx0;
-        const bool tl = tile_of(s, t, tn_, ty0, tx0);
+        const bool t1 = C::NT == 2 && t != 0;
+        const int tn_ = t1 ? tns[C::NT - 1] : tns[0], ty0 = t1 ? ty0s[C::NT - 1] : ty0s[0], tx0 = t1 ? tx0s[C::NT - 1] : tx0s[0];
+        const bool tl = t1 ? tlive[C::NT - 1] : tlive[0];
         const u32x4 v = *reinterpret_cast<const u32x4*>(smem + C::C_OFF + t * C::CB + o * C::CROW + (((j ^ (o >> 1)) & (PPO - 1)) << 4));
         if (tl)
           *reinterpret_cast<u32x4*>(p.out + ((long long)(tn_ * 2 * p.Hs + 2 * ty0 + (o >> 5)) * (2 * p.Ws) + 2 * tx0 + (o & 31)) * N + j * 8) = v;
       }
     }
     if constexpr (STATS) {
-      if (tid < C::NT) {  // one record per tile: the 8 / NT waves of that tile
-        int tn_, ty0, tx0;
-        if (tile_of(s, tid, tn_, ty0, tx0)) {
-          double S1 = 0.0, S2 = 0.0;
+      // the first wave of each tile adds the per-thread partials of that tile's waves (fp64 from here on) while the other
+      // waves are still writing rows: one cross-lane reduction per tile instead of one per wave
+      const int t = wid / (8 / C::NT);
+      if (wid == t * (8 / C::NT)) {
+        double S1 = 0.0, S2 = 0.0;
 #pragma unroll
-          for (int w = 0; w < 8; ++w) {
-            const bool mine = C::WN == 2 ? true : ((w >> 2) == tid);
-            if (mine) { S1 += sred[((s & 1) * 8 + w) * 2]; S2 += sred[((s & 1) * 8 + w) * 2 + 1]; }
-          }
+        for (int w = 0; w < 8 / C::NT; ++w) {
+          const f32x2 v = sstat[(t * (8 / C::NT) + w) * 64 + lane];
+          S1 += (double)v[0]; S2 += (double)v[1];
+        }
+        S1 = lg_wave_sum_d(S1); S2 = lg_wave_sum_d(S2);
+        const bool t1 = C::NT == 2 && t != 0;
+        const bool tl = t1 ? tlive[C::NT - 1] : tlive[0];
+        const int sy0 = t1 ? ty0s[C::NT - 1] : ty0s[0], sx0 = t1 ? tx0s[C::NT - 1] : tx0s[0], sn = t1 ? tns[C::NT - 1] : tns[0];
+        if (lane == 0 && tl) {
           constexpr double cnt = (double)(C::OPX * N);
           const double md = S1 / cnt;
-          const int tin = (ty0 / TH) * p.tpi_x + tx0 / TW;
-          double* o = p.spart + ((long long)tn_ * p.tpi + tin) * 3;
+          const int tin = (sy0 / TH) * p.tpi_x + sx0 / TW;
+          double* o = p.spart + ((long long)sn * p.tpi + tin) * 3;
           o[0] = cnt; o[1] = (double)sbias[0] + md; o[2] = S2 - cnt * md * md;
         }
       }
     }
     (void)live;
+    U3_STAMP();  // rows out
     __syncthreads();  // next halo complete, staging area free again
   }
 }
@@ -344,6 +367,9 @@ extern "C" int lg_conv_up3_try(const void* src16, const void* wpack_up, const fl
   const long long nitems = (long long)B * p.tpi;
   if (nitems <= 0 || nitems >= (1ll << 30)) return LG_ERR_UNSUPPORTED;
   p.nitems = (int)nitems;
+#ifdef LG_U3_STAMPS
+  { const char* e = getenv("LG_U3_STAMPBUF"); p.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
   const bool stats = spart && nparts_out && (size_t)B * p.tpi * 3 * sizeof(double) <= spart_bytes;
   p.spart = stats ? (double*)spart : nullptr;
   hipStream_t st = (hipStream_t)stream;
