@@ -65,7 +65,7 @@ extern "C" int lg_conv_fwd_stats_fused(int up, int dtype, int B, int Hs, int Ws,
   if (B <= 0 || Hs <= 0 || Ws <= 0) return 0;
   if (cb == 3) return (!up && dtype == LG_DT_BF16 && n3_enabled() && lg_n3_conv1_p16_supported(Hs, Ws, cs)) ? 1 : 0;
   if (getenv("LG_NO_HALO")) return 0;
-  if ((long long)Hs * Ws < 128) return 0;  // several samples per 128-row tile: no per-sample record
+  if ((long long)Hs * Ws < 128 && !(Hs == 8 && Ws == 8)) return 0;  // > 2 samples per 128-row tile: no per-sample record
   return up ? lg_conv_halo_supported(1, dtype, B, Hs, Ws, cs, cb) : lg_conv_halo_supported(0, dtype, B, Hs, Ws, cb, cs);
 }
 

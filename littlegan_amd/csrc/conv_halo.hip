@@ -483,6 +483,59 @@ __global__ __launch_bounds__(256, (W3 ? LG_EXP_W3OCC : 2)) void conv_halo_kernel
     // ---- fused InstanceNormalization moments of this block's output tile (one sample per block: NI == 1) ----------
     // {count, mean, M2 about the block mean}, merged per sample with Chan's formula by stats_final_kernel (norm.hip):
     // the separate pass that re-read the whole conv output for its moments is gone.
+    if (p.spart && !(p.dbg & 32) && p.NI == 2) {
+      // two samples per block (8 x 8 maps): 32-row fragment f = wm*MT + i belongs to sample f >> 1; one record per sample
+      float s2[2] = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + (wn * NT + j) * 32 + r;
+        if (col < p.N) {
+          const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s2[((wm * MT + i) >> 1) & 1] += acc[i][j][e] + bv;
+        }
+      }
+      __syncthreads();
+      const int ncol = min(BN, p.N - n0);
+      const double cnt = 64.0 * (double)ncol;
+      double red[2] = {(double)s2[0], (double)s2[1]};
+      lg_block_sum_d<2>(red, sred);
+      if (tid == 0) { sred[32] = red[0] / cnt; sred[33] = red[1] / cnt; }
+      __syncthreads();
+      const float mean0 = (float)sred[32], mean1 = (float)sred[33];
+      float m2[2] = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + (wn * NT + j) * 32 + r;
+        if (col < p.N) {
+          const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const int sm = ((wm * MT + i) >> 1) & 1;
+            const float mean = sm ? mean1 : mean0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { const float d = (acc[i][j][e] + bv) - mean; m2[sm] += d * d; }
+          }
+        }
+      }
+      const double md0 = sred[32], md1 = sred[33];
+      double red2[2] = {(double)m2[0], (double)m2[1]};
+      lg_block_sum_d<2>(red2, sred);
+      if (tid == 0) {
+        const int part = cls * p.ntn + tile_n;  // one tile per image
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm) {
+          if (img0 + sm < p.B) {
+            double* o = p.spart + ((long long)(img0 + sm) * p.nparts + part) * 3;
+            const double meand = sm ? md1 : md0, df = (double)(sm ? mean1 : mean0) - meand;
+            o[0] = cnt; o[1] = meand; o[2] = red2[sm] - cnt * df * df;
+          }
+        }
+      }
+      if constexpr (RES) __syncthreads();
+    } else
     if (p.spart && !(p.dbg & 32)) {
       float s = 0.f;
 #pragma unroll
@@ -671,7 +724,7 @@ extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const voi
     p.cfg = cfg;
   }
   int nparts = 0;  // set by launch<> to the partial records per sample of the tiling it chose
-  if (spart && nparts_out && p.NI == 1 && act == 0) {
+  if (spart && nparts_out && (p.NI == 1 || (p.NI == 2 && p.TH * p.TW == 64)) && act == 0) {
     const int worst = (mode == MODE_UP ? 4 : 1) * p.tpi * (p.Npad / 32);  // narrowest column tile
     if ((size_t)B * worst * 3 * sizeof(double) <= spart_bytes) { p.spart = (double*)spart; p.nparts_host = &nparts; }
   }
