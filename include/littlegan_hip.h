@@ -154,6 +154,26 @@ int lg_instnorm_leaky_apply_z16(const void* z16, const float* stats, const void*
 int lg_instnorm_leaky_bwd_z16(const void* z16, const float* stats, const void* g, int g_is_bf16, float* dx, void* dx16,
                               float* dgamma, float* dbeta, float* db, int C, void* workspace, size_t ws_bytes, int B,
                               long long L, int pre_leaky, int post_leaky, float alpha, int accumulate, void* stream);
+/* same; partials / nparts_in (may be null / 0): the sums of the first pass as [B][nparts_in][2] doubles, already written by
+ * the conv epilogue that produced g (lg_*_dgrad_nf below) - that pass is then skipped */
+int lg_instnorm_leaky_bwd_z16_p(const void* z16, const float* stats, const void* g, int g_is_bf16, float* dx, void* dx16,
+                                float* dgamma, float* dbeta, float* db, int C, const void* partials, int nparts_in,
+                                void* workspace, size_t ws_bytes, int B, long long L, int pre_leaky, int post_leaky, float alpha,
+                                int accumulate, void* stream);
+/* data gradients of the bf16 activation path that ALSO write the first-pass sums of the InstanceNormalization backward of
+ * the layer the gradient belongs to (z16 / stats: that layer's bf16 conv output and statistics records; instance.py:105-128,
+ * model.py:22-24,46-50): *nparts > 0 -> part holds [B][*nparts][2] doubles for lg_instnorm_leaky_bwd_z16_p; 0 -> not
+ * produced for this shape (the gradient itself is always written).  part_bytes >= lg_conv_stats_workspace_bytes(...). */
+int lg_conv2d_s2_dgrad_nf(const void* dy16, const void* pack, void* dx16, int B, int Hs, int Ws, int cb, int cs,
+                          const void* z16, const float* stats, float alpha, void* part, size_t part_bytes, int* nparts,
+                          void* stream);
+int lg_convT_s2_dgrad_nf(const void* dy16, const void* pack, void* dx16, int B, int Hs, int Ws, int cb, int cs,
+                         const void* z16, const float* stats, float alpha, void* part, size_t part_bytes, int* nparts,
+                         void* stream);
+int lg_convT_s1_tanh_bwd_nf(const float* x, const void* x16, const float* dpre, const void* pack, void* dx16, float* dw,
+                            float* db, void* workspace, size_t ws_bytes, int B, int H, int W, int cb, int cs, int accumulate,
+                            int dtype, const void* z16, const float* stats, float alpha, void* part, size_t part_bytes,
+                            int* nparts, void* stream);
 
 /* ---- tf.compat.v1.layers.Dense  model.py:62-63 (heads, sigmoid), :83, :120 ----------------------- */
 int lg_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, void* stream);

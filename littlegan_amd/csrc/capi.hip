@@ -144,6 +144,48 @@ extern "C" int lg_convT_s2_dgrad_m16(const float* dy, const void* dy16, const vo
   return lg_conv_igemm_ex(MODE_DOWN, dtype, dy, dy16, pack, nullptr, dx, dx16, B, Hs, Ws, cb, cs, 0, 0, 0, nullptr, 0, nullptr,
                           stream);
 }
+// ---- data gradients that also emit the norm-backward sums of the gradient they write (bf16 activation path) -----------
+// The gradient g = dL/dh of the layer BELOW feeds that layer's InstanceNormalization backward, whose first pass needs
+// per-sample sums over (z, g).  Given that layer's bf16 conv output z16 and statistics records, the kernels that cover
+// the shape add the sums to their epilogue: *nparts > 0 records per sample in part ([B][*nparts][2] doubles), to be
+// handed to lg_instnorm_leaky_bwd_z16_p.  *nparts == 0: not produced (shape not covered) - run the ordinary backward.
+extern "C" int lg_conv_up3_nf_try(const void* src16, const void* wpack_up, const float* bias, void* out16, int B, int Hm, int Wm,
+                                  int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, const LgNormFuse* nf,
+                                  size_t nf_bytes, void* stream);
+extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const float* bias, void* out16, int B, int Hm, int Wm,
+                                    int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, const LgNormFuse* nf,
+                                    size_t nf_bytes, void* stream);
+extern "C" int lg_n3_s1_dgrad_p16_nf_try(const float* dpre, const float* w, float* dx, void* dx16, int B, int H, int W, int N,
+                                         const LgNormFuse* nf, size_t nf_bytes, int* nparts_out, void* stream);
+
+extern "C" int lg_conv2d_s2_dgrad_nf(const void* dy16, const void* pack, void* dx16, int B, int Hs, int Ws, int cb, int cs,
+                                     const void* z16, const float* stats, float alpha, void* part, size_t part_bytes,
+                                     int* nparts, void* stream) {
+  LG_CHECK_ARG(dy16 && pack && dx16 && nparts, "lg_conv2d_s2_dgrad_nf: null pointer");
+  *nparts = 0;
+  if (cb != 3 && z16 && stats && part && n3_enabled()) {
+    LgNormFuse nf{(const __bf16*)z16, stats, (double*)part, alpha, 0};
+    const int rc = lg_conv_up3_nf_try(dy16, up_pack(pack, cb, cs, LG_DT_BF16), nullptr, dx16, B, Hs, Ws, cs, cb, nullptr, 0, nparts,
+                                      &nf, part_bytes, stream);
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+    *nparts = 0;
+  }
+  return lg_conv2d_s2_dgrad_m16(nullptr, dy16, pack, nullptr, dx16, B, Hs, Ws, cb, cs, LG_DT_BF16, stream);
+}
+extern "C" int lg_convT_s2_dgrad_nf(const void* dy16, const void* pack, void* dx16, int B, int Hs, int Ws, int cb, int cs,
+                                    const void* z16, const float* stats, float alpha, void* part, size_t part_bytes,
+                                    int* nparts, void* stream) {
+  LG_CHECK_ARG(dy16 && pack && dx16 && nparts, "lg_convT_s2_dgrad_nf: null pointer");
+  *nparts = 0;
+  if (cb != 3 && z16 && stats && part) {
+    LgNormFuse nf{(const __bf16*)z16, stats, (double*)part, alpha, 0};
+    const int rc = lg_conv_down3_nf_try(dy16, pack, nullptr, dx16, B, Hs, Ws, cb, cs, nullptr, 0, nparts, &nf, part_bytes, stream);
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+    *nparts = 0;
+  }
+  return lg_convT_s2_dgrad_m16(nullptr, dy16, pack, nullptr, dx16, B, Hs, Ws, cb, cs, LG_DT_BF16, stream);
+}
+
 extern "C" int lg_conv2d_s2_wgrad_m16(const float* x, const void* x16, const float* dy, const void* dy16, float* dw,
                                       void* workspace, size_t ws_bytes, int B, int Hs, int Ws, int cb, int cs,
                                       int accumulate, int dtype, void* stream) {
@@ -250,9 +292,29 @@ extern "C" int lg_convT_s1_tanh_bwd(const float* x, const float* dpre, const voi
 
 // x16 (optional, bf16 path): bf16 mirror of x read by the weight-gradient kernel (x may then be null where
 // lg_n3_m16_supported); dx16 (optional): the data gradient is written as bf16 there instead of fp32 to dx
+static int s1_tanh_bwd_impl(const float* x, const void* x16, const float* dpre, const void* pack, float* dx, void* dx16,
+                            float* dw, float* db, void* workspace, size_t ws_bytes, int B, int H, int W, int cb, int cs,
+                            int accumulate, int dtype, const LgNormFuse* nf, size_t nf_bytes, int* nparts, void* stream);
 extern "C" int lg_convT_s1_tanh_bwd_m16(const float* x, const void* x16, const float* dpre, const void* pack, float* dx,
                                         void* dx16, float* dw, float* db, void* workspace, size_t ws_bytes, int B, int H,
                                         int W, int cb, int cs, int accumulate, int dtype, void* stream) {
+  return s1_tanh_bwd_impl(x, x16, dpre, pack, dx, dx16, dw, db, workspace, ws_bytes, B, H, W, cb, cs, accumulate, dtype, nullptr, 0,
+                          nullptr, stream);
+}
+// as lg_convT_s1_tanh_bwd_m16 (bf16 data gradient dx16) + the norm-backward sums of dx16 (see lg_conv2d_s2_dgrad_nf)
+extern "C" int lg_convT_s1_tanh_bwd_nf(const float* x, const void* x16, const float* dpre, const void* pack, void* dx16, float* dw,
+                                       float* db, void* workspace, size_t ws_bytes, int B, int H, int W, int cb, int cs,
+                                       int accumulate, int dtype, const void* z16, const float* stats, float alpha, void* part,
+                                       size_t part_bytes, int* nparts, void* stream) {
+  LG_CHECK_ARG(nparts, "lg_convT_s1_tanh_bwd_nf: null pointer");
+  *nparts = 0;
+  LgNormFuse nf{(const __bf16*)z16, stats, (double*)part, alpha, 0};
+  return s1_tanh_bwd_impl(x, x16, dpre, pack, nullptr, dx16, dw, db, workspace, ws_bytes, B, H, W, cb, cs, accumulate, dtype,
+                          (z16 && stats && part && dx16) ? &nf : nullptr, part_bytes, nparts, stream);
+}
+static int s1_tanh_bwd_impl(const float* x, const void* x16, const float* dpre, const void* pack, float* dx, void* dx16,
+                            float* dw, float* db, void* workspace, size_t ws_bytes, int B, int H, int W, int cb, int cs,
+                            int accumulate, int dtype, const LgNormFuse* nf, size_t nf_bytes, int* nparts, void* stream) {
   LG_CHECK_ARG(cb == 3, "lg_convT_s1_tanh_bwd: only image_channel == 3 is supported (got %d)", cb);
   LG_CHECK_ARG(dpre && pack && workspace, "lg_convT_s1_tanh_bwd: null pointer");
   LG_CHECK_ARG(ws_bytes >= lg_convT_s1_bwd_workspace_bytes(B, H, W, cb, cs, dtype),
@@ -262,7 +324,7 @@ extern "C" int lg_convT_s1_tanh_bwd_m16(const float* x, const void* x16, const f
   if (dx || dx16) {  // dx[i,ci] = sum_k,co dpre[i+k-2,co] W[k,co,ci]  -> patch conv, stride 1, pad 2
     rc = LG_ERR_UNSUPPORTED;
     if (dtype == LG_DT_BF16 && n3_enabled())
-      rc = lg_n3_s1_dgrad_p16_try(dpre, raw_pack(pack, cb, cs, dtype), dx, dx16, B, H, W, cs, stream);
+      rc = lg_n3_s1_dgrad_p16_nf_try(dpre, raw_pack(pack, cb, cs, dtype), dx, dx16, B, H, W, cs, nf, nf_bytes, nparts, stream);
     if (rc == LG_ERR_UNSUPPORTED) rc = lg_conv_igemm_ex(MODE_PATCH, dtype, dpre, nullptr, pack, nullptr, dx, dx16, B, H, W, 3, cs, 0, 1, 2, nullptr, 0,
                           nullptr, stream);
     if (rc) return rc;

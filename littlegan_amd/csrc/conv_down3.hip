@@ -52,6 +52,7 @@ struct D3Params {
   double* spart;       // [B][nparts][3] or null
   int B, Hs, Ws, Cs, Hm, Wm, N, N32, KB;
   int tpi_x, tpi, ntn, nitems, nparts;
+  LgNormFuse nf;       // FUSE instantiation: norm-backward sums of the produced gradient (lg_common.h)
   int stagger;         // start delay of the odd-slot block in ~1024-cycle units
   unsigned long long* stamps;  // diagnostic build only (LG_D3_STAMPS): [block][64] s_memtime stamps of wave 0
 };
@@ -67,8 +68,9 @@ constexpr int toff_bytes(int t) {  // tap t = ky*5+kx: LDS byte offset of its so
   return ((t / 5) * HWP + ((t % 5) >> 1) + ((t % 5) & 1) * HWH) * ROWB;
 }
 
-template <bool STATS>
+template <bool STATS, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
+  static_assert(!(STATS && FUSE), "forward moments and backward sums are never needed together");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* sred = reinterpret_cast<double*>(smem + SRED_OFF);
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -264,11 +266,23 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
       }
       __syncthreads();  // tile complete in LDS (and the wave sums)
       const long long obase = ((long long)(cur.n * p.Hm + cur.y0) * p.Wm + cur.x0) * p.N + cur.tn * 128;
+      float nf1 = 0.f, nf2 = 0.f;
+      (void)nf1; (void)nf2;
 #pragma unroll
       for (int q8 = 0; q8 < 8; ++q8) {
         const int piece = tid + q8 * 256, row = piece >> 4, j = piece & 15;
         const u32x4 v = *reinterpret_cast<const u32x4*>(C + row * 256 + ((j ^ (row & 15)) << 4));
-        *reinterpret_cast<u32x4*>(p.out + obase + ((long long)(row >> 4) * p.Wm + (row & 15)) * p.N + j * 8) = v;
+        const long long goff = obase + ((long long)(row >> 4) * p.Wm + (row & 15)) * p.N + j * 8;
+        *reinterpret_cast<u32x4*>(p.out + goff) = v;
+        if constexpr (FUSE) {
+          const u32x4 zq = *reinterpret_cast<const u32x4*>(p.nf.z + goff);
+          const float* sp = p.nf.stats + (long long)cur.n * 8;
+          lg_nf_accum(v, zq, sp[0], sp[4], sp[2], sp[3], p.nf.alpha, nf1, nf2);
+        }
+      }
+      if constexpr (FUSE) {
+        const double w1 = lg_wave_sum_d((double)nf1), w2 = lg_wave_sum_d((double)nf2);
+        if (lane == 0) { sred[(k & 1) * 8 + wid] = w1; sred[(k & 1) * 8 + 4 + wid] = w2; }
       }
       if constexpr (STATS) {
         if (tid == 0) {
@@ -282,6 +296,14 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
         }
       }
       __syncthreads();  // C fully read before the buffer is staged again (sred alternates between two sets of slots)
+      if constexpr (FUSE) {
+        if (tid == 0) {
+          const double* q = sred + (k & 1) * 8;
+          const int tin = (cur.y0 / TH) * p.tpi_x + cur.x0 / TW;
+          double* o = p.nf.part + ((long long)cur.n * p.nparts + tin * p.ntn + cur.tn) * 2;
+          o[0] = (q[0] + q[1]) + (q[2] + q[3]); o[1] = (q[4] + q[5]) + (q[6] + q[7]);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -302,8 +324,17 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
 }  // namespace
 
 // LG_OK: launched.  LG_ERR_UNSUPPORTED: the caller falls back to the halo-tile kernel of conv_halo.hip.
+extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const float* bias, void* out16, int B, int Hm, int Wm,
+                                    int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, const LgNormFuse* nf,
+                                    size_t nf_bytes, void* stream);
 extern "C" int lg_conv_down3_try(const void* src16, const void* wpack, const float* bias, void* out16, int B, int Hm, int Wm,
                                  int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, void* stream) {
+  return lg_conv_down3_nf_try(src16, wpack, bias, out16, B, Hm, Wm, Cs, N, spart, spart_bytes, nparts_out, nullptr, 0, stream);
+}
+// nf (optional; data-gradient use): also the norm-backward sums of the produced gradient ([B][*nparts_out][2] doubles)
+extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const float* bias, void* out16, int B, int Hm, int Wm,
+                                    int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, const LgNormFuse* nf,
+                                    size_t nf_bytes, void* stream) {
   if (nparts_out) *nparts_out = 0;
   static int off = -1;
   if (off < 0) off = getenv("LG_NO_DOWN3") ? 1 : 0;  // A/B switch
@@ -320,8 +351,10 @@ extern "C" int lg_conv_down3_try(const void* src16, const void* wpack, const flo
 #ifdef LG_D3_STAMPS
   { const char* e = getenv("LG_D3_STAMPBUF"); p.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
-  const bool stats = spart && nparts_out && (size_t)B * p.nparts * 3 * sizeof(double) <= spart_bytes;
+  const bool fuse = nf && nf->z && nf->stats && nf->part && nparts_out && (size_t)B * p.nparts * 2 * sizeof(double) <= nf_bytes;
+  const bool stats = !fuse && spart && nparts_out && (size_t)B * p.nparts * 3 * sizeof(double) <= spart_bytes;
   p.spart = stats ? (double*)spart : nullptr;
+  if (fuse) p.nf = *nf;
   static int nblk = 0;
   if (!nblk) {
     int dev = 0, cus = 256;
@@ -332,13 +365,15 @@ extern "C" int lg_conv_down3_try(const void* src16, const void* wpack, const flo
     nblk = 2 * cus;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_down3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_down3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   }
   const int grid = p.nitems < nblk ? p.nitems : nblk;
   hipStream_t st = (hipStream_t)stream;
-  if (stats) hipLaunchKernelGGL(conv_down3_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, st, p);
+  if (fuse) hipLaunchKernelGGL((conv_down3_kernel<false, true>), dim3(grid), dim3(256), LDS_BYTES, st, p);
+  else if (stats) hipLaunchKernelGGL(conv_down3_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, st, p);
   else hipLaunchKernelGGL(conv_down3_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, st, p);
   LG_CHECK_LAUNCH("lg_conv_down3");
-  if (stats) *nparts_out = p.nparts;
+  if (stats || fuse) *nparts_out = p.nparts;
   return LG_OK;
 }
 

@@ -52,6 +52,7 @@ struct U3Params {
   __bf16* out;         // [B][2Hs][2Ws][N]
   double* spart;       // [B][tpi][3] or null
   int B, Hs, Ws, tpi_x, tpi, nitems;
+  LgNormFuse nf;       // FUSE instantiation: norm-backward sums of the produced gradient (lg_common.h)
   unsigned long long* stamps;  // diagnostic build (LG_U3_STAMPS): [block][8 waves][32]
 };
 
@@ -68,8 +69,9 @@ constexpr int ntaps_of(int cls) { return nk(cls >> 1) * nk(cls & 1); }
 constexpr int tap_k(int p, int a) { return p ? 2 * a : 2 * a + 1; }
 constexpr int tap_d(int p, int a) { return (p + 1 - tap_k(p, a)) / 2; }
 
-template <int CS, int N, bool STATS>
+template <int CS, int N, bool STATS, bool FUSE = false>
 __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
+  static_assert(!(STATS && FUSE), "forward moments and backward sums are never needed together");
   using C = Cfg<CS, N>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x2* sstat = reinterpret_cast<f32x2*>(smem + C::SRED_OFF);
@@ -284,6 +286,8 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
     for (int t = 0; t < C::NT; ++t) tlive[t] = tile_of(s, t, tns[t], ty0s[t], tx0s[t]);
     // ---- whole output rows out: 16 rows x (32 pixels x N channels) contiguous, 16 B per lane ------------------------------
     {
+      float nf1 = 0.f, nf2 = 0.f;
+      (void)nf1; (void)nf2;
       constexpr int PPO = C::CROW / 16;                 // pieces per output pixel (8 | 4)
       constexpr int TOT = C::NT * C::OPX * PPO;         // 4096 pieces per step either way
 #pragma unroll
@@ -295,8 +299,36 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
         const int tn_ = t1 ? tns[C::NT - 1] : tns[0], ty0 = t1 ? ty0s[C::NT - 1] : ty0s[0], tx0 = t1 ? tx0s[C::NT - 1] : tx0s[0];
         const bool tl = t1 ? tlive[C::NT - 1] : tlive[0];
         const u32x4 v = *reinterpret_cast<const u32x4*>(smem + C::C_OFF + t * C::CB + o * C::CROW + (((j ^ (o >> 1)) & (PPO - 1)) << 4));
-        if (tl)
-          *reinterpret_cast<u32x4*>(p.out + ((long long)(tn_ * 2 * p.Hs + 2 * ty0 + (o >> 5)) * (2 * p.Ws) + 2 * tx0 + (o & 31)) * N + j * 8) = v;
+        const long long goff = ((long long)(tn_ * 2 * p.Hs + 2 * ty0 + (o >> 5)) * (2 * p.Ws) + 2 * tx0 + (o & 31)) * N + j * 8;
+        if (tl) *reinterpret_cast<u32x4*>(p.out + goff) = v;
+        if constexpr (FUSE) {
+          if (tl) {
+            const u32x4 zq = *reinterpret_cast<const u32x4*>(p.nf.z + goff);
+            const float* sp = p.nf.stats + (long long)tn_ * 8;
+            lg_nf_accum(v, zq, sp[0], sp[4], sp[2], sp[3], p.nf.alpha, nf1, nf2);
+          }
+        }
+      }
+      if constexpr (FUSE) sstat[tid] = f32x2{nf1, nf2};
+    }
+    if constexpr (FUSE) {
+      __syncthreads();
+      const int t = wid / (8 / C::NT);
+      if (wid == t * (8 / C::NT)) {
+        double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8 / C::NT; ++w) {
+          const f32x2 v = sstat[(t * (8 / C::NT) + w) * 64 + lane];
+          S1 += (double)v[0]; S2 += (double)v[1];
+        }
+        S1 = lg_wave_sum_d(S1); S2 = lg_wave_sum_d(S2);
+        const bool t1 = C::NT == 2 && t != 0;
+        const bool tl = t1 ? tlive[C::NT - 1] : tlive[0];
+        const int sy0 = t1 ? ty0s[C::NT - 1] : ty0s[0], sx0 = t1 ? tx0s[C::NT - 1] : tx0s[0], sn = t1 ? tns[C::NT - 1] : tns[0];
+        if (lane == 0 && tl) {
+          double* o = p.nf.part + ((long long)sn * p.tpi + (sy0 / TH) * p.tpi_x + sx0 / TW) * 2;
+          o[0] = S1; o[1] = S2;
+        }
       }
     }
     if constexpr (STATS) {
@@ -330,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
 }
 
 template <int CS, int N>
-int launch_up3(U3Params p, bool stats, hipStream_t st) {
+int launch_up3(U3Params p, bool stats, hipStream_t st, bool fuse = false) {
   using C = Cfg<CS, N>;
   static int nblk = 0;
   if (!nblk) {
@@ -342,10 +374,12 @@ int launch_up3(U3Params p, bool stats, hipStream_t st) {
     nblk = cus;  // one 8-wave workgroup per CU
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, true>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
   }
   const int nsteps = (p.nitems + C::NT - 1) / C::NT;
   const int grid = nsteps < nblk ? nsteps : nblk;
-  if (stats) hipLaunchKernelGGL((conv_up3_kernel<CS, N, true>), dim3(grid), dim3(512), C::LDS, st, p);
+  if (fuse) hipLaunchKernelGGL((conv_up3_kernel<CS, N, false, true>), dim3(grid), dim3(512), C::LDS, st, p);
+  else if (stats) hipLaunchKernelGGL((conv_up3_kernel<CS, N, true>), dim3(grid), dim3(512), C::LDS, st, p);
   else hipLaunchKernelGGL((conv_up3_kernel<CS, N, false>), dim3(grid), dim3(512), C::LDS, st, p);
   return LG_OK;
 }
@@ -357,8 +391,18 @@ extern "C" int lg_conv_up3_supported(int B, int Hm, int Wm, int Cs, int N) {
 }
 
 // LG_OK: launched.  LG_ERR_UNSUPPORTED: the caller falls back to conv_halo.hip.  *nparts_out = records per sample (tiles).
+extern "C" int lg_conv_up3_nf_try(const void* src16, const void* wpack_up, const float* bias, void* out16, int B, int Hm, int Wm,
+                                  int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, const LgNormFuse* nf,
+                                  size_t nf_bytes, void* stream);
 extern "C" int lg_conv_up3_try(const void* src16, const void* wpack_up, const float* bias, void* out16, int B, int Hm, int Wm,
                                int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, void* stream) {
+  return lg_conv_up3_nf_try(src16, wpack_up, bias, out16, B, Hm, Wm, Cs, N, spart, spart_bytes, nparts_out, nullptr, 0, stream);
+}
+// nf (optional; data-gradient use): also writes the norm-backward sums of the produced gradient, *nparts_out = records
+// per sample in nf->part ([B][nparts][2] doubles, nf_bytes available)
+extern "C" int lg_conv_up3_nf_try(const void* src16, const void* wpack_up, const float* bias, void* out16, int B, int Hm, int Wm,
+                                  int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, const LgNormFuse* nf,
+                                  size_t nf_bytes, void* stream) {
   if (nparts_out) *nparts_out = 0;
   if (!src16 || !wpack_up || !out16 || !lg_conv_up3_supported(B, Hm, Wm, Cs, N)) return LG_ERR_UNSUPPORTED;
   U3Params p{};
@@ -370,12 +414,14 @@ extern "C" int lg_conv_up3_try(const void* src16, const void* wpack_up, const fl
 #ifdef LG_U3_STAMPS
   { const char* e = getenv("LG_U3_STAMPBUF"); p.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
-  const bool stats = spart && nparts_out && (size_t)B * p.tpi * 3 * sizeof(double) <= spart_bytes;
+  const bool fuse = nf && nf->z && nf->stats && nf->part && nparts_out && (size_t)B * p.tpi * 2 * sizeof(double) <= nf_bytes;
+  const bool stats = !fuse && spart && nparts_out && (size_t)B * p.tpi * 3 * sizeof(double) <= spart_bytes;
   p.spart = stats ? (double*)spart : nullptr;
+  if (fuse) p.nf = *nf;
   hipStream_t st = (hipStream_t)stream;
-  if (Cs == 128) launch_up3<128, 64>(p, stats, st);
-  else launch_up3<64, 32>(p, stats, st);
+  if (Cs == 128) launch_up3<128, 64>(p, stats, st, fuse);
+  else launch_up3<64, 32>(p, stats, st, fuse);
   LG_CHECK_LAUNCH("lg_conv_up3");
-  if (stats) *nparts_out = p.tpi;
+  if (stats || fuse) *nparts_out = p.tpi;
   return LG_OK;
 }

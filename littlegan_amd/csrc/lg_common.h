@@ -106,4 +106,30 @@ __device__ __forceinline__ void lg_block_sum_d(double (&v)[NV], double* smem) {
   }
 }
 
+// ---- norm-backward sums fused into the epilogue of the data-gradient conv that PRODUCES the gradient g -------------
+// The InstanceNormalization backward of the layer below needs, per sample, S1 = sum g' and S2 = sum g'*c with
+// c = z - mu, g' = LeakyReLU'(a*c + b) * g  (norm.hip, bwd_partial).  z, the statistics record and g (as it is STORED, i.e.
+// bf16) are all at hand where the conv writes g, so the separate pass that re-read z and g is dropped.
+// part: [B][nparts][2] doubles, one record per (sample, block tile), merged by bwd_final_kernel.
+struct LgNormFuse {
+  const __bf16* z;     // raw conv output of the layer the gradient belongs to, same shape / layout as g
+  const float* stats;  // its statistics records [B][8] = {mu_hi, sigma, a, beta, mu_lo, ...}
+  double* part;
+  float alpha;
+  int nparts;
+};
+// 8 consecutive channels of one pixel: g8 / z8 = 16 B of bf16 each
+__device__ __forceinline__ void lg_nf_accum(const u32x4 g8, const u32x4 z8, float mu, float mul, float a, float b, float alpha,
+                                            float& s1, float& s2) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float g0 = __builtin_bit_cast(float, g8[k] << 16), g1 = __builtin_bit_cast(float, g8[k] & 0xffff0000u);
+    const float z0 = __builtin_bit_cast(float, z8[k] << 16), z1 = __builtin_bit_cast(float, z8[k] & 0xffff0000u);
+    const float c0 = (z0 - mu) - mul, c1 = (z1 - mu) - mul;
+    const float p0 = (a * c0 + b > 0.f) ? g0 : alpha * g0, p1 = (a * c1 + b > 0.f) ? g1 : alpha * g1;
+    s1 += p0; s1 += p1;
+    s2 = __builtin_fmaf(p0, c0, s2); s2 = __builtin_fmaf(p1, c1, s2);
+  }
+}
+
 static inline int lg_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -168,11 +168,12 @@ __global__ __launch_bounds__(256) void up_p16_kernel(const __bf16* __restrict__ 
 // the C tiles go through LDS and leave as 16-B-per-lane stores of whole contiguous rows; the conv1 form also emits
 // the per-block InstanceNorm moments {count, mean, M2} (same record as conv_halo.hip) so no pass re-reads z.
 // --------------------------------------------------------------------------------------------------------------
-template <int S, int N, bool OUT16, bool STATS>
+template <int S, int N, bool OUT16, bool STATS, bool FUSE = false>
 __global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict__ src, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         __bf16* __restrict__ out16, double* __restrict__ spart, int B,
-                                                        int H, int W, int pad) {
+                                                        int H, int W, int pad, LgNormFuse nf = LgNormFuse{}) {
+  static_assert(!FUSE || (OUT16 && !STATS), "norm-backward sums: bf16 data-gradient form only");
   constexpr int NT = N / 16, HSIDE = S * (TS - 1) + 5, ROWF = HSIDE * 3, TROWS = HSIDE + 2;
   constexpr int MTW = TS / 4;  // m-tiles (tile rows of 16 pixels) per wave
   __shared__ __attribute__((aligned(16))) float tile[TROWS * ROWF + 4];
@@ -220,6 +221,8 @@ __global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict_
 
     // one m-tile (a tile row of 16 pixels) at a time: MFMAs -> + bias -> moments -> wave-private LDS transpose -> whole
     // contiguous rows out, 16 B per lane.  No block barrier in here: LDS operations of one wave execute in order.
+    float nf1 = 0.f, nf2 = 0.f;  // FUSE: norm-backward sums of the gradient this tile writes (lg_common.h)
+    (void)nf1; (void)nf2;
     float s1 = 0.f, s2 = 0.f;  // sum and sum of squares about `shift` (the first bias: close enough to the block mean)
     const float shift = STATS ? (bias ? bias[0] : 0.f) : 0.f;
     float* cw = cst[wid];
@@ -258,6 +261,11 @@ __global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict_
           v[0] = (__bf16)a[0]; v[1] = (__bf16)a[1]; v[2] = (__bf16)a[2]; v[3] = (__bf16)a[3];
           v[4] = (__bf16)b[0]; v[5] = (__bf16)b[1]; v[6] = (__bf16)b[2]; v[7] = (__bf16)b[3];
           *reinterpret_cast<bf16x8*>(out16 + o0 + idx * 8) = v;
+          if constexpr (FUSE) {
+            const u32x4 zq = *reinterpret_cast<const u32x4*>(nf.z + o0 + idx * 8);
+            const float* sp = nf.stats + (long long)n * 8;
+            lg_nf_accum(__builtin_bit_cast(u32x4, v), zq, sp[0], sp[4], sp[2], sp[3], nf.alpha, nf1, nf2);
+          }
         }
       } else {
 #pragma unroll
@@ -269,6 +277,14 @@ __global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict_
       __builtin_amdgcn_wave_barrier();
     }
 
+    if constexpr (FUSE) {  // one record per (sample, tile): S1 = sum g', S2 = sum g' c
+      double red[2] = {(double)nf1, (double)nf2};
+      lg_block_sum_d<2>(red, sred);
+      if (threadIdx.x == 0) {
+        double* o = nf.part + ((long long)n * tpi + tt) * 2;
+        o[0] = red[0]; o[1] = red[1];
+      }
+    }
     if constexpr (STATS) {  // moments of this block's 256 x N outputs (one sample per block): {count, mean, M2}
       const double cnt = 256.0 * N;
       double red[2] = {(double)s1, (double)s2};
@@ -330,12 +346,27 @@ extern "C" int lg_n3_conv1_fwd_p16_try(const float* img, const float* w, const f
 }
 
 // data gradient of the final stride-1 layer: dpre [B,H,W,3] fp32 -> dx [B,H,W,32] as bf16 (dx16) or fp32 (dx)
+extern "C" int lg_n3_s1_dgrad_p16_nf_try(const float* dpre, const float* w, float* dx, void* dx16, int B, int H, int W, int N,
+                                         const LgNormFuse* nf, size_t nf_bytes, int* nparts_out, void* stream);
 extern "C" int lg_n3_s1_dgrad_p16_try(const float* dpre, const float* w, float* dx, void* dx16, int B, int H, int W, int N,
                                       void* stream) {
+  return lg_n3_s1_dgrad_p16_nf_try(dpre, w, dx, dx16, B, H, W, N, nullptr, 0, nullptr, stream);
+}
+// nf (optional, bf16 output): also the norm-backward sums of the produced gradient, [B][*nparts_out][2] doubles
+extern "C" int lg_n3_s1_dgrad_p16_nf_try(const float* dpre, const float* w, float* dx, void* dx16, int B, int H, int W, int N,
+                                         const LgNormFuse* nf, size_t nf_bytes, int* nparts_out, void* stream) {
+  if (nparts_out) *nparts_out = 0;
   if (H % TS || W % TS || N != 32 || !dpre || !w || (!dx && !dx16)) return LG_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  const int ntiles = B * (H / TS) * (W / TS);
+  const int tpi_ = (H / TS) * (W / TS);
+  const int ntiles = B * tpi_;
   const dim3 grid(ntiles < 4096 ? ntiles : 4096);
+  if (dx16 && nf && nf->z && nf->stats && nf->part && nparts_out && (size_t)B * tpi_ * 2 * sizeof(double) <= nf_bytes) {
+    hipLaunchKernelGGL((patch_p16_kernel<1, 32, true, false, true>), grid, dim3(256), 0, st, dpre, w, nullptr, nullptr, (__bf16*)dx16, nullptr, B, H, W, 2, *nf);
+    LG_CHECK_LAUNCH("lg_n3_s1_dgrad_p16(nf)");
+    *nparts_out = tpi_;
+    return LG_OK;
+  }
   if (dx16) hipLaunchKernelGGL((patch_p16_kernel<1, 32, true, false>), grid, dim3(256), 0, st, dpre, w, nullptr, nullptr, (__bf16*)dx16, nullptr, B, H, W, 2);
   else hipLaunchKernelGGL((patch_p16_kernel<1, 32, false, false>), grid, dim3(256), 0, st, dpre, w, nullptr, dx, nullptr, nullptr, B, H, W, 2);
   LG_CHECK_LAUNCH("lg_n3_s1_dgrad_p16");

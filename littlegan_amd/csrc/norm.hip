@@ -681,11 +681,24 @@ extern "C" int lg_instnorm_leaky_apply_z16(const void* z16, const float* stats, 
   return LG_OK;
 }
 
+extern "C" int lg_instnorm_leaky_bwd_z16_p(const void* z16, const float* stats, const void* g, int g_is_bf16, float* dx,
+                                           void* dx16, float* dgamma, float* dbeta, float* db, int C, const void* partials,
+                                           int nparts_in, void* workspace, size_t ws_bytes, int B, long long L, int pre_leaky,
+                                           int post_leaky, float alpha, int accumulate, void* stream);
 // as lg_instnorm_leaky_bwd_db with x given as bf16 (workspace: lg_instnorm_bwd_db_workspace_bytes)
 extern "C" int lg_instnorm_leaky_bwd_z16(const void* z16, const float* stats, const void* g, int g_is_bf16, float* dx,
                                          void* dx16, float* dgamma, float* dbeta, float* db, int C, void* workspace,
                                          size_t ws_bytes, int B, long long L, int pre_leaky, int post_leaky, float alpha,
                                          int accumulate, void* stream) {
+  return lg_instnorm_leaky_bwd_z16_p(z16, stats, g, g_is_bf16, dx, dx16, dgamma, dbeta, db, C, nullptr, 0, workspace, ws_bytes, B, L,
+                                     pre_leaky, post_leaky, alpha, accumulate, stream);
+}
+// partials / nparts_in (optional): the per-sample sums {sum g', sum g' c} as [B][nparts_in][2] doubles, already produced by
+// the epilogue of the conv that wrote g (lg_conv2d_s2_dgrad_nf, ...): the first (partial-sums) pass over z and g is skipped
+extern "C" int lg_instnorm_leaky_bwd_z16_p(const void* z16, const float* stats, const void* g, int g_is_bf16, float* dx,
+                                           void* dx16, float* dgamma, float* dbeta, float* db, int C, const void* partials,
+                                           int nparts_in, void* workspace, size_t ws_bytes, int B, long long L, int pre_leaky,
+                                           int post_leaky, float alpha, int accumulate, void* stream) {
   LG_CHECK_ARG(z16 && stats && g && (dx || dx16) && workspace, "lg_instnorm_leaky_bwd_z16: null pointer");
   LG_CHECK_ARG(B > 0 && B <= 65535 && L > 0 && L % 8 == 0 && (long long)B * L / 8 < (1LL << 31),
                "lg_instnorm_leaky_bwd_z16: bad shape B=%d L=%lld", B, L);
@@ -705,13 +718,18 @@ extern "C" int lg_instnorm_leaky_bwd_z16(const void* z16, const float* stats, co
   double* partial = (double*)ws;
   float* bstats = (float*)(ws + part_bytes(B, L));
   double* gsum = (double*)(ws + part_bytes(B, L) + bst_bytes(B));
-  if (g_is_bf16)
-    hipLaunchKernelGGL(bwd_partial16_kernel<true>, dim3(nc, B), dim3(256), 0, st, x, g, stats, partial, L, nc, pre_leaky,
-                       post_leaky, alpha);
-  else
-    hipLaunchKernelGGL(bwd_partial16_kernel<false>, dim3(nc, B), dim3(256), 0, st, x, g, stats, partial, L, nc, pre_leaky,
-                       post_leaky, alpha);
-  LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd_z16(partial)");
+  if (partials && nparts_in > 0) {  // sums fused into the producer of g
+    partial = (double*)partials;
+    nc = nparts_in;
+  } else {
+    if (g_is_bf16)
+      hipLaunchKernelGGL(bwd_partial16_kernel<true>, dim3(nc, B), dim3(256), 0, st, x, g, stats, partial, L, nc, pre_leaky,
+                         post_leaky, alpha);
+    else
+      hipLaunchKernelGGL(bwd_partial16_kernel<false>, dim3(nc, B), dim3(256), 0, st, x, g, stats, partial, L, nc, pre_leaky,
+                         post_leaky, alpha);
+    LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd_z16(partial)");
+  }
   hipLaunchKernelGGL(bwd_final_kernel, dim3(B), dim3(64), 0, st, (const double*)partial, stats, bstats, gsum, L, nc);
   LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd_z16(final)");
   if (dgamma && dbeta) {

@@ -171,6 +171,7 @@ class Encoder(_ConvStack):
         levels = set(range(1, 5)) if (need_wgrad and wgrad_levels is None) else (set(wgrad_levels or ()) if need_wgrad else set())
         lowest = 1 if need_input_grad else (min(levels) if levels else 5)
         any_wgrad = need_wgrad
+        nfp = None  # first-pass sums of this level's norm backward, if the conv that wrote g_h produced them
         for i in range(4, lowest - 1, -1):
             need_wgrad = any_wgrad and i in levels
             cb, cs = self.chans[i - 1]
@@ -194,13 +195,24 @@ class Encoder(_ConvStack):
                 drop32 = m16 and ops.n3_m16_supported(z.shape[1], z.shape[2], cb, cs, self.dtype)
                 dz16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if drop32 else None
             dz = ops.instnorm_bwd(z, st, g_h, dgm, dbt, 0, 1, a, out16=dz16, want_f32=not drop32,
-                                  db=self._g[f"conv{i}.bias"] if need_wgrad else None)  # bias gradient = column sums of dz
+                                  db=self._g[f"conv{i}.bias"] if need_wgrad else None,  # bias gradient = column sums of dz
+                                  partials=nfp)
+            nfp = None
             if need_wgrad:
                 ops.conv2d_s2_wgrad(x, dz, self._g[f"conv{i}.kernel"], False, self.dtype, x16=x16, dy16=dz16)
             # the gradient handed to the next (lower) level's norm backward stays bf16 in the bf16 path; the image
             # gradient of level 1 is fp32 (consumed by the loss / tanh backward)
-            g_h = (ops.conv2d_s2_dgrad(dz, packs[i - 1], cb, self.dtype, dy16=dz16, out_bf16=(self.dtype == DT_BF16 and i > 1))
-                   if want_dx else None)
+            if not want_dx:
+                g_h = None
+            elif m16 and i > 1 and drop32 and i - 1 >= lowest:
+                # bf16 path: the conv that writes the gradient of level i-1 also adds up the first-pass sums of that level's
+                # norm backward (its z and statistics are at hand) where the kernel covers the shape
+                zl, stl = ctx["enc"][i - 2][1], ctx["enc"][i - 2][2]
+                if rows is not None:
+                    zl, stl = zl[rows], stl[rows]
+                g_h, nfp = ops.conv2d_s2_dgrad(None, packs[i - 1], cb, self.dtype, dy16=dz16, out_bf16=True, fuse=(zl, stl, a))
+            else:
+                g_h = ops.conv2d_s2_dgrad(dz, packs[i - 1], cb, self.dtype, dy16=dz16, out_bf16=(self.dtype == DT_BF16 and i > 1))
         return g_h if need_input_grad else None
 
 
@@ -258,8 +270,9 @@ class Decoder(_ConvStack):
             ctx["dec"] = saved
         return x, x16
 
-    def backward(self, ctx, g_h, need_wgrad: bool, wgrad_levels=None, need_input_grad: bool = True):
-        """g_h: fp32 or (bf16 path) bf16.  Returns the gradient w.r.t. the decoder input x (skip tensors receive the same gradient as the
+    def backward(self, ctx, g_h, need_wgrad: bool, wgrad_levels=None, need_input_grad: bool = True, partials=None):
+        """partials: first-pass sums of level 4's norm backward if the conv that wrote g_h produced them (ops.NormPartials).
+        g_h: fp32 or (bf16 path) bf16.  Returns the gradient w.r.t. the decoder input x (skip tensors receive the same gradient as the
         level input they were added to; no tape of the step asks for it), or None if need_input_grad is False.
         wgrad_levels / need_input_grad: as Encoder.backward — the chain stops at the lowest level anything is asked of."""
         a = self.args.leaky_alpha
@@ -267,6 +280,7 @@ class Decoder(_ConvStack):
         levels = set(range(1, 5)) if (need_wgrad and wgrad_levels is None) else (set(wgrad_levels or ()) if need_wgrad else set())
         lowest = 1 if need_input_grad else (min(levels) if levels else 5)
         any_wgrad = need_wgrad
+        nfp = partials
         for i in range(4, lowest - 1, -1):
             need_wgrad = any_wgrad and i in levels
             cb, cs = self.chans[i - 1]
@@ -277,12 +291,18 @@ class Decoder(_ConvStack):
             drop32 = (dz16 is not None and (not need_wgrad or x16 is not None) and
                       ops.conv_halo_supported(0, self.dtype, z.shape[0], z.shape[1] // 2, z.shape[2] // 2, cb, cs))
             dz = ops.instnorm_bwd(z, st, g_h, dgm, dbt, 0, 1, a, out16=dz16, want_f32=not drop32,
-                                  db=self._g[f"conv{i}.bias"] if need_wgrad else None)
+                                  db=self._g[f"conv{i}.bias"] if need_wgrad else None, partials=nfp)
+            nfp = None
             if need_wgrad:
                 ops.convT_s2_wgrad(x, dz, self._g[f"conv{i}.kernel"], False, self.dtype, x16=x16, dy16=dz16)
             want_dx = i > lowest or (i == 1 and need_input_grad)
-            g_h = (ops.convT_s2_dgrad(dz, packs[i - 1], cs, self.dtype, dy16=dz16, out_bf16=(self.dtype == DT_BF16 and i > 1))
-                   if want_dx else None)
+            if not want_dx:
+                g_h = None
+            elif dz16 is not None and drop32 and i > 1 and i - 1 >= lowest:
+                zl, stl = ctx["dec"][i - 2][1], ctx["dec"][i - 2][2]  # the level the gradient belongs to
+                g_h, nfp = ops.convT_s2_dgrad(None, packs[i - 1], cs, self.dtype, dy16=dz16, out_bf16=True, fuse=(zl, stl, a))
+            else:
+                g_h = ops.convT_s2_dgrad(dz, packs[i - 1], cs, self.dtype, dy16=dz16, out_bf16=(self.dtype == DT_BF16 and i > 1))
         return g_h if need_input_grad else None
 
 
@@ -307,17 +327,22 @@ class _FinalConv(_Module):
     def __call__(self, x, out=None, x16=None):
         return ops.convT_s1_tanh_fwd(x, self.pack(), self._w["bias"], self.cb, self.dtype, out=out, x16=x16)
 
-    def backward(self, x, dpre, need_wgrad: bool, x16=None, need_dx: bool = True):
-        """Returns dL/dx: fp32, or bf16 in the bf16 path (the decoder's norm backward reads either); None if not need_dx."""
+    def backward(self, x, dpre, need_wgrad: bool, x16=None, need_dx: bool = True, fuse=None):
+        """Returns dL/dx: fp32, or bf16 in the bf16 path (the decoder's norm backward reads either); None if not need_dx.
+        fuse = (z16, stats, alpha) of the decoder's last level (bf16 path): returns (dx, NormPartials | None) instead."""
         B, H, W, _ = dpre.shape
         g16 = self.dtype == DT_BF16
         dx = torch.empty(B, H, W, self.cs, dtype=torch.bfloat16 if g16 else torch.float32, device=dpre.device) if need_dx else None
         if not need_dx and not need_wgrad:
-            return None
-        ops.convT_s1_tanh_bwd(x if need_wgrad else None, dpre, self.pack(), self.cs, self.dtype,
-                              dx=None if (g16 or not need_dx) else dx, dx16=dx if (g16 and need_dx) else None,
-                              dw=self._g["kernel"] if need_wgrad else None,
-                              db=self._g["bias"] if need_wgrad else None, x16=x16 if need_wgrad else None)
+            return (None, None) if fuse is not None else None
+        use_fuse = fuse is not None and g16 and need_dx and fuse[0].dtype == torch.bfloat16
+        r = ops.convT_s1_tanh_bwd(x if need_wgrad else None, dpre, self.pack(), self.cs, self.dtype,
+                                  dx=None if (g16 or not need_dx) else dx, dx16=dx if (g16 and need_dx) else None,
+                                  dw=self._g["kernel"] if need_wgrad else None,
+                                  db=self._g["bias"] if need_wgrad else None, x16=x16 if need_wgrad else None,
+                                  fuse=fuse if use_fuse else None)
+        if fuse is not None:
+            return (dx, r[1] if use_fuse else None)
         return dx
 
 
@@ -393,9 +418,11 @@ class Generator(_Module):
         levels = [i for i in range(1, 5) if lo <= 4 * i and 4 * i + 4 <= hi]
         dn = lo <= 0 and hi >= 4
         below_final = dn or bool(levels)
-        g = self.conv.backward(ctx["xdec"], dpre, need_wgrad=final, x16=ctx.get("xdec16"), need_dx=below_final)
+        z4, st4 = ctx["dec"][3][1], ctx["dec"][3][2]
+        g, nfp = self.conv.backward(ctx["xdec"], dpre, need_wgrad=final, x16=ctx.get("xdec16"), need_dx=below_final,
+                                    fuse=(z4, st4, self.args.leaky_alpha))
         if below_final:
-            g = self.decoder.backward(ctx, g, need_wgrad=bool(levels), wgrad_levels=levels, need_input_grad=dn)
+            g = self.decoder.backward(ctx, g, need_wgrad=bool(levels), wgrad_levels=levels, need_input_grad=dn, partials=nfp)
             if dn:
                 self._dn.backward(ctx, g)
 
@@ -520,8 +547,9 @@ class Adjuster(_Module):
 
     def backward_own(self, ctx, dpre):
         """Gradient w.r.t. Adjuster.weights[16:20] only (eager_trainer.py:51,62,163)."""
-        g = self.conv.backward(None, dpre, need_wgrad=False)
-        g = self.decoder.backward(ctx, g, need_wgrad=False)
+        z4, st4 = ctx["dec"][3][1], ctx["dec"][3][2]
+        g, nfp = self.conv.backward(None, dpre, need_wgrad=False, fuse=(z4, st4, self.args.leaky_alpha))
+        g = self.decoder.backward(ctx, g, need_wgrad=False, partials=nfp)
         self._dn.backward(ctx, g)
 
 

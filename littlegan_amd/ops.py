@@ -110,10 +110,45 @@ def conv2d_s2_fwd(x, pack, bias, cs, dtype, out=None):
     return out
 
 
-def conv2d_s2_dgrad(dy, pack, cb, dtype, out=None, dy16=None, out_bf16=False):
+class NormPartials:
+    """First-pass sums of an InstanceNormalization backward, produced by the epilogue of the conv that wrote the gradient
+    (lg_*_dgrad_nf): `buf` holds [B][nparts][2] doubles.  Valid until the next fused data gradient is enqueued (one
+    shared workspace; kernels of a stream run in order and the consumer is the very next norm backward)."""
+
+    def __init__(self, buf, nparts):
+        self.buf, self.nparts = buf, nparts
+
+
+def _nf_args(fuse, B, up, Hs, Ws, N, device):
+    """fuse = (z16, stats, alpha) of the layer the produced gradient belongs to -> ctypes arguments + result holder"""
+    import ctypes
+    z16, st, alpha = fuse
+    if z16.dtype != torch.bfloat16 or not z16.is_contiguous() or z16.shape[0] != B:
+        raise ValueError("fuse: z16 must be the contiguous bf16 conv output of the layer below")
+    _chk(st, (B, NSTAT), "fuse stats")
+    lib = _lib.load()
+    ws = workspace(int(lib.lg_conv_stats_workspace_bytes(int(up), B, Hs, Ws, N)), device, "nfpart")
+    return z16, st, float(alpha), ws, ctypes.c_int(0)
+
+
+def conv2d_s2_dgrad(dy, pack, cb, dtype, out=None, dy16=None, out_bf16=False, fuse=None):
     """dx [B,2Hs,2Ws,cb]; out_bf16: return the gradient as a bf16 tensor (no fp32 copy is written).
-    dy may be None when its bf16 mirror dy16 is given and the halo kernel covers the shape (conv_halo_supported)."""
+    dy may be None when its bf16 mirror dy16 is given and the halo kernel covers the shape (conv_halo_supported).
+    fuse = (z16, stats, alpha) (bf16 path, out_bf16): the kernel also writes the first-pass sums of the norm backward the
+    gradient feeds; returns (dx, NormPartials or None)."""
     B, Hs, Ws, cs = (dy if dy is not None else dy16).shape
+    if fuse is not None:
+        import ctypes
+        if not (out_bf16 and dy16 is not None and dtype == DT_BF16):
+            raise ValueError("conv2d_s2_dgrad: fuse needs the bf16 path (dy16, out_bf16)")
+        _chk16(dy16, dy16, "dy16")
+        out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.bfloat16, device=dy16.device)
+        z16, st, alpha, ws, npo = _nf_args(fuse, B, True, Hs, Ws, cb, dy16.device)
+        e0 = _pb()
+        check(_lib.load().lg_conv2d_s2_dgrad_nf(_p(dy16), _p(pack), _p(out), B, Hs, Ws, cb, cs, _p(z16), _p(st), alpha, _p(ws),
+                                               ws.numel(), ctypes.addressof(npo), _stream()), "lg_conv2d_s2_dgrad_nf")
+        _pe(e0, "conv_igemm_up", 50.0 * B * Hs * Ws * cb * cs)
+        return out, (NormPartials(ws, npo.value) if npo.value > 0 else None)
     if dy is not None:
         _chk(dy, name="dy")
     if dy16 is not None:
@@ -184,8 +219,21 @@ def convT_s2_fwd(x, pack, bias, cb, dtype, out=None):
     return out
 
 
-def convT_s2_dgrad(dy, pack, cs, dtype, out=None, dy16=None, out_bf16=False):
+def convT_s2_dgrad(dy, pack, cs, dtype, out=None, dy16=None, out_bf16=False, fuse=None):
+    """fuse: as conv2d_s2_dgrad -> returns (dx, NormPartials or None)"""
     B, H, W, cb = (dy if dy is not None else dy16).shape
+    if fuse is not None:
+        import ctypes
+        if not (out_bf16 and dy16 is not None and dtype == DT_BF16):
+            raise ValueError("convT_s2_dgrad: fuse needs the bf16 path (dy16, out_bf16)")
+        _chk16(dy16, dy16, "dy16")
+        out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.bfloat16, device=dy16.device)
+        z16, st, alpha, ws, npo = _nf_args(fuse, B, False, H // 2, W // 2, cs, dy16.device)
+        e0 = _pb()
+        check(_lib.load().lg_convT_s2_dgrad_nf(_p(dy16), _p(pack), _p(out), B, H // 2, W // 2, cb, cs, _p(z16), _p(st), alpha,
+                                              _p(ws), ws.numel(), ctypes.addressof(npo), _stream()), "lg_convT_s2_dgrad_nf")
+        _pe(e0, "conv_igemm_down", 50.0 * B * (H // 2) * (W // 2) * cb * cs)
+        return out, (NormPartials(ws, npo.value) if npo.value > 0 else None)
     if dy is not None:
         _chk(dy, name="dy")
     if dy16 is not None:
@@ -235,8 +283,10 @@ def convT_s1_tanh_fwd(x, pack, bias, cb, dtype, out=None, x16=None):
     return out
 
 
-def convT_s1_tanh_bwd(x, dpre, pack, cs, dtype, dx=None, dw=None, db=None, accumulate=False, x16=None, dx16=None):
-    """x16: bf16 mirror of x for the weight gradient; dx16: bf16 tensor that receives the data gradient instead of dx."""
+def convT_s1_tanh_bwd(x, dpre, pack, cs, dtype, dx=None, dw=None, db=None, accumulate=False, x16=None, dx16=None, fuse=None):
+    """x16: bf16 mirror of x for the weight gradient; dx16: bf16 tensor that receives the data gradient instead of dx.
+    fuse = (z16, stats, alpha) (with dx16): also the first-pass sums of the norm backward dx16 feeds -> returns
+    (dx16, NormPartials or None)."""
     lib = _lib.load()
     B, H, W, cb = dpre.shape
     _chk(dpre, name="dpre")
@@ -256,6 +306,15 @@ def convT_s1_tanh_bwd(x, dpre, pack, cs, dtype, dx=None, dw=None, db=None, accum
         _chk(db, (cb,), "db")
     nbytes = int(lib.lg_convT_s1_bwd_workspace_bytes(B, H, W, cb, cs, dtype))
     ws = workspace(nbytes, dpre.device, "wgrad")
+    if fuse is not None:
+        import ctypes
+        if dx16 is None or dx is not None:
+            raise ValueError("convT_s1_tanh_bwd: fuse needs the bf16 data gradient (dx16)")
+        z16, st, alpha, wsp, npo = _nf_args(fuse, B, False, H, W, cs, dpre.device)
+        check(lib.lg_convT_s1_tanh_bwd_nf(_p(x), _p(x16), _p(dpre), _p(pack), _p(dx16), _p(dw), _p(db), _p(ws), ws.numel(), B, H, W,
+                                          cb, cs, int(accumulate), dtype, _p(z16), _p(st), alpha, _p(wsp), wsp.numel(),
+                                          ctypes.addressof(npo), _stream()), "lg_convT_s1_tanh_bwd_nf")
+        return dx16, (NormPartials(wsp, npo.value) if npo.value > 0 else None)
     check(lib.lg_convT_s1_tanh_bwd_m16(_p(x), _p(x16), _p(dpre), _p(pack), _p(dx), _p(dx16), _p(dw), _p(db), _p(ws),
                                        ws.numel(), B, H, W, cb, cs, int(accumulate), dtype, _stream()),
           "lg_convT_s1_tanh_bwd_m16")
@@ -358,7 +417,7 @@ def instnorm_apply(x, stats, skip, pre_leaky, post_leaky, alpha, out=None, out16
 
 
 def instnorm_bwd(x, stats, g, dgamma, dbeta, pre_leaky, post_leaky, alpha, accumulate=False, out=None, out16=None,
-                 want_f32=True, db=None):
+                 want_f32=True, db=None, partials=None):
     """g may be fp32 or bf16 (as written by a bf16 data-gradient conv); x fp32, or the bf16 conv output of the bf16
     activation path.  Returns the fp32 dx (or None if want_f32 is False, in which case only the bf16 mirror out16 is
     written).  db [C] (optional, C = x.shape[-1]): receives the column sums of dx = the bias gradient of the conv
@@ -396,6 +455,14 @@ def instnorm_bwd(x, stats, g, dgamma, dbeta, pre_leaky, post_leaky, alpha, accum
         C = x.shape[-1]
         _chk(db, (C,), "db")
     ws = workspace(int(lib.lg_instnorm_bwd_db_workspace_bytes(B, Ln, C)), x.device, "small")
+    if partials is not None:  # NormPartials from the conv that produced g: the first pass over (x, g) is skipped
+        if not x_is16:
+            raise ValueError("instnorm_bwd: fused partial sums belong to the bf16 activation path")
+        check(lib.lg_instnorm_leaky_bwd_z16_p(_p(x), _p(stats), _p(g), int(g16), _p(out), _p(out16), _p(dgamma), _p(dbeta), _p(db), C,
+                                              _p(partials.buf), int(partials.nparts), _p(ws), ws.numel(), B, Ln, int(pre_leaky),
+                                              int(post_leaky), float(alpha), int(accumulate), _stream()),
+              "lg_instnorm_leaky_bwd_z16_p")
+        return out
     fn = lib.lg_instnorm_leaky_bwd_z16 if x_is16 else lib.lg_instnorm_leaky_bwd_db
     check(fn(_p(x), _p(stats), _p(g), int(g16), _p(out), _p(out16), _p(dgamma), _p(dbeta), _p(db), C, _p(ws), ws.numel(), B, Ln,
              int(pre_leaky), int(post_leaky), float(alpha), int(accumulate), _stream()), "lg_instnorm_leaky_bwd")
