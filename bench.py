@@ -199,11 +199,11 @@ def main():
         # HBM-side bytes per launch of that kernel class: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) cannot run inside
         # this process; they are collected on this same command and committed (scripts/pmc_traffic.py)
         traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_traffic.json")
         if a.workload == "c3" and world == 1 and os.path.exists(tpath):
             rec = json.load(open(tpath)).get(tag)
             if rec:
-                traffic, traffic_src = rec["bytes_per_launch"], "profiles/r1_pmc_traffic.json (rocprofv3 --pmc, offline)"
+                traffic, traffic_src = rec["bytes_per_launch"], "profiles/r2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, offline)"
         conv_sec = sum(v[2] for v in prof.values())
         conv_fl = sum(v[1] for v in prof.values())
         out = {

@@ -3,7 +3,7 @@
 usage: python scripts/pmc_traffic.py F_counter_collection.csv W_counter_collection.csv out.json
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: both counters are in KB;
 on gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane) coalesced reads -> doubled; WRITE_SIZE is exact
-for 16-B streaming stores (the conv epilogue stores are 4 B/lane: uncalibrated, taken as reported).
+for 16-B streaming stores (the conv epilogue stores of conv_halo.hip are 4..16 B/lane, those of conv_down3 / conv_up3 16 B/lane).
 Tags are those of littlegan_amd.ops.Profile (bench.py reports the dominant one)."""
 import collections
 import csv
@@ -12,6 +12,10 @@ import sys
 
 
 def tag_of(name):
+    if "conv_down3_kernel" in name:
+        return "conv_igemm_down"
+    if "conv_up3_kernel" in name:
+        return "conv_igemm_up"
     if "conv_halo_kernel" in name:
         if "conv_halo_kernelIDF16bLi0E" in name or "conv_halo_kernelIfLi0E" in name or "conv_halo_kernel<__bf16, 0" in name or "conv_halo_kernel<float, 0" in name:
             return "conv_igemm_down"
