@@ -226,6 +226,13 @@ int lg_augment_drawn(const float* img, float* out, int B, int H, int W, float db
                      float noise_scale, unsigned long long seed, unsigned long long draw_offset,
                      unsigned long long noise_offset, void* workspace, size_t ws_bytes, void* stream);
 
+/* ---- FID activation statistics  fid.py:185-188 ----------------------------------------------- */
+/* mu[D] = mean over the N samples, sigma[D][D] = np.cov(act, rowvar=False) (divisor N - 1) of act[N][D] (fp32), both fp64
+ * on the device; Gram matrix of the centred activations on the fp64 matrix instruction.  N >= 2. */
+size_t lg_fid_stats_workspace_bytes(long long N, int D);
+int lg_fid_stats(const float* act, long long N, int D, double* mu, double* sigma, void* workspace, size_t ws_bytes,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,8 @@ SIGNATURES = {
     "lg_randn": (I, [P, L, F, F, L, L, P]),
     "lg_augment_workspace_bytes": (Z, [I]),
     "lg_augment": (I, [P, P, I, I, I, P, F, F, F, F, L, L, P, Z, P]),
+    "lg_fid_stats_workspace_bytes": (Z, [L, I]),
+    "lg_fid_stats": (I, [P, L, I, P, P, P, Z, P]),
     "lg_augment_drawn_workspace_bytes": (Z, [I]),
     "lg_augment_drawn": (I, [P, P, I, I, I, F, F, F, F, F, L, L, L, P, Z, P]),
 }

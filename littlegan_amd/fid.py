@@ -3,7 +3,7 @@
 Only the arithmetic: d^2 = |mu1 - mu2|^2 + tr(S1 + S2 - 2 (S1 S2)^(1/2)).  The Inception pool_3 activations it is
 normally fed with need a frozen graph that the reference downloads (fid.py:276) and this pipeline cannot obtain, so
 the entry points take activation matrices.  The O(N D^2) part (mean and covariance of [N, D] activations) runs on the
-device in fp64; the D x D matrix square root stays on the host (scipy), as in the reference."""
+device in fp64 (in-tree kernel on the fp64 matrix instruction, csrc/fid.hip); the D x D matrix square root stays on the host (scipy), as in the reference."""
 import warnings
 
 import numpy as np
@@ -11,10 +11,15 @@ import torch
 
 
 def activation_statistics(act: torch.Tensor):
-    """fid.py:185-188: mu = mean over samples, sigma = np.cov(act, rowvar=False) (divisor N - 1).  act [N, D], any
-    device; the reduction is done where the tensor lives, in float64."""
+    """fid.py:185-188: mu = mean over samples, sigma = np.cov(act, rowvar=False) (divisor N - 1).  act [N, D].
+    On the GPU this is the in-tree fp64-MFMA kernel (csrc/fid.hip, lg_fid_stats); a host tensor (tests, tiny inputs) is
+    reduced with torch in float64."""
     if act.dim() != 2 or act.shape[0] < 2:
         raise ValueError("activation_statistics: need an [N >= 2, D] matrix")
+    if act.is_cuda:
+        from . import ops
+        mu, sigma = ops.fid_stats(act.to(torch.float32).contiguous())
+        return mu.cpu().numpy(), sigma.cpu().numpy()
     a = act.to(torch.float64)
     mu = a.mean(dim=0)
     c = a - mu

@@ -718,3 +718,17 @@ def augment_drawn(img, db_max, c_lo, c_hi, dh_max, noise_scale, seed, draw_offse
                                float(noise_scale), _i64(seed), _i64(draw_offset), _i64(noise_offset), _p(ws), ws.numel(),
                                _stream()), "lg_augment_drawn")
     return out
+
+
+def fid_stats(act):
+    """fid.py:185-188 on the device: (mu [D], sigma [D, D]) fp64 tensors of act [N, D] (fp32 CUDA)."""
+    if act.dim() != 2 or act.shape[0] < 2:
+        raise ValueError("fid_stats: need an [N >= 2, D] matrix")
+    _chk(act, name="act")
+    N, D = act.shape
+    mu = torch.empty(D, dtype=torch.float64, device=act.device)
+    sigma = torch.empty(D, D, dtype=torch.float64, device=act.device)
+    lib = _lib.load()
+    ws = workspace(int(lib.lg_fid_stats_workspace_bytes(N, D)), act.device, "small")
+    check(lib.lg_fid_stats(_p(act), N, D, _p(mu), _p(sigma), _p(ws), ws.numel(), _stream()), "lg_fid_stats")
+    return mu, sigma

@@ -47,7 +47,7 @@ def main():
         wr = wt[t] / wc[t] if wc[t] else 0.0
         res[t] = {"read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                   "bytes_per_launch": round(rd + wr), "launches_sampled": fc[t]}
-    res["_note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 2 --warmup 1 "
+    res["_note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 2 --warmup 11 "
                     "--no-cpu-baseline`; FETCH_SIZE doubled (gfx950 wide-read correction), averages over all launches of the tag")
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))

@@ -54,3 +54,19 @@ def test_statistics_on_the_device():
     an = a.double().cpu().numpy()
     assert np.allclose(mu, an.mean(0), atol=1e-12) and np.allclose(sigma, np.cov(an, rowvar=False), atol=1e-10)
     assert abs(fid_from_activations(a, a)) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D", [(1000, 2048), (777, 192), (33, 70)])
+def test_in_tree_covariance_kernel_matches_numpy(N, D):
+    """lg_fid_stats (csrc/fid.hip, fp64 matrix instruction) against np.mean / np.cov of the same fp32 activations, incl.
+    a feature count that is not a multiple of the 64-wide tile and a sample count that is not a multiple of the slab."""
+    g = torch.Generator(device="cuda").manual_seed(N)
+    a = torch.randn(N, D, device="cuda", generator=g) * 3.0 + 1.5
+    from littlegan_amd import ops
+    mu, sigma = ops.fid_stats(a)
+    an = a.double().cpu().numpy()
+    assert np.abs(mu.cpu().numpy() - an.mean(0)).max() < 1e-12
+    ref = np.cov(an, rowvar=False)
+    assert np.abs(sigma.cpu().numpy() - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
+    assert torch.equal(sigma, sigma.t())
