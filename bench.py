@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="time the C2 CPU shape at its full batch 64 (minutes)")
+    ap.add_argument("--graph", action="store_true", help="time EagerTrainer.graph_step (captured HIP graphs) instead of eager launches")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo: rehearsal of the N>1 path")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo; RCCL refuses it)")
@@ -171,15 +172,22 @@ def main():
         torch.cuda.synchronize()
 
     b0 = 11  # batch_no > 10 so the Adjuster branch runs (eager_trainer.py:152); every 5th step is a partition step
+    step = tr.graph_step if a.graph else tr.train_step_from_inputs
     for i in range(a.warmup):
-        tr.train_step_from_inputs(b0 + i, inp)
+        step(b0 + i, inp)
     barrier()
-    ops.Profile.start()
+    if not a.graph:
+        ops.Profile.start()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        tr.train_step_from_inputs(b0 + a.warmup + i, inp)
+        step(b0 + a.warmup + i, inp)
     barrier()
     dt = time.perf_counter() - t0
+    if a.graph:  # per-launch HIP events cannot sit inside a replayed graph: the roofline leg times 5 eager steps afterwards
+        ops.Profile.start()
+        for i in range(5):
+            tr.train_step_from_inputs(b0 + a.warmup + a.steps + i, inp)
+        torch.cuda.synchronize()
     prof = ops.Profile.stop()
     if world > 1:
         import torch.distributed as dist
@@ -216,13 +224,14 @@ def main():
                                     "c2": "C2: 128x128x3 synthetic CelebA, batch 64/GPU, exact-f32 MFMA, G+D step only",
                                     "c5": "C5 (per-GPU share): 256x256x3 synthetic CelebA, batch 256/GPU, bf16 MFMA + Adjuster branch"}[a.workload],
                        "global_batch": gb, "per_gpu_batch": args.batch_size, "image": args.init_dim * 16, "cond_dim": 40,
-                       "parallelism": f"dp{world}", "consumed_samples_per_step": 2 * gb},
+                       "parallelism": f"dp{world}", "consumed_samples_per_step": 2 * gb,
+                       "launch": "hipGraph replay (one graph per step kind)" if a.graph else "eager launches"},
             "roofline": {"bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": PEAK[dt_name], "unit": "TFLOP/s",
                          "frac": round(ach / PEAK[dt_name], 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
                          "launches": n, "avg_launch_ms": round(sec / n * 1e3, 4),
                          "all_conv_kernels": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 2),
-                                                  "ms_per_step": round(v[2] / a.steps * 1e3, 3)} for k, v in prof.items()},
+                                                  "ms_per_step": round(v[2] / (5 if a.graph else a.steps) * 1e3, 3)} for k, v in prof.items()},
                          "conv_share_of_step": round(conv_sec / dt, 3),
                          "conv_tflops_overall": round(conv_fl / conv_sec / 1e12, 2),
                          "step_algorithmic_tflops": round(GFLOP_PER_IMAGE[a.workload] * args.batch_size / ms, 2)},

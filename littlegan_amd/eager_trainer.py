@@ -160,6 +160,44 @@ class EagerTrainer:
         self.store.bump()
         return (fake, adj_image, self.losses["gen"], self.losses["disc"], self.losses["adj"] if run_adj else None)
 
+    # ------------------------------------------------------------------ the same step as a replayed HIP graph
+    def step_kind(self, batch_no: int):
+        """Steps with the same kind enqueue the same kernels on the same shapes: (partition group or -1, Adjuster on)."""
+        a = self.args
+        part = (batch_no // (a.partition_interval + 1)) % 3 if (a.use_partition and batch_no % (a.partition_interval + 1) == 0) else -1
+        return part, bool(a.train_adj and batch_no > 10)
+
+    def graph_step(self, batch_no: int, inp: Dict[str, torch.Tensor]):
+        """train_step_from_inputs through a captured HIP graph, one graph per step kind (full step, the three partition
+        groups, with / without the Adjuster branch).  The C ABI allocates nothing and never synchronises, so the whole
+        step (~330 launches) is capturable; the first step of a kind runs eagerly (it is a real training step and sizes
+        every workspace), the graph is captured right after it and every later step of that kind is one replay.
+        Results are bit-identical to the eager path (tests/test_step_gpu.py::test_graph_replay_is_bit_exact).
+        Single-GPU only: with data parallelism the all-reduces stay on the eager path."""
+        if self.sync.enabled:
+            return self.train_step_from_inputs(batch_no, inp)
+        kind = self.step_kind(batch_no)
+        if not hasattr(self, "_graphs"):
+            self._graphs, self._graph_pool, self._graph_seen = {}, None, set()
+            self._graph_in = {k: torch.empty_like(v) for k, v in inp.items()}
+        for k, v in inp.items():
+            self._graph_in[k].copy_(v)
+        if kind not in self._graphs:
+            if kind not in self._graph_seen:  # first step of this kind: eager (sizes workspaces, builds every lazy static)
+                self._graph_seen.add(kind)
+                return self.train_step_from_inputs(batch_no, self._graph_in)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            ops.Profile.enabled = False
+            with torch.cuda.graph(g, pool=self._graph_pool):   # records the launches, executes nothing
+                out = self.train_step_from_inputs(batch_no, self._graph_in)
+            self._graphs[kind] = (g, out)
+        g, out = self._graphs[kind]
+        g.replay()
+        return out
+
     # ------------------------------------------------------------------ eager_trainer.py:115-169
     def _train_step(self, batch_no, iterator):
         try:

@@ -236,6 +236,26 @@ def test_step_full_channels_one_step(mfma, init_dim):
         check_emu(tr, cfg, W, 11, inp, fake, adj, lg, ld, la)
 
 
+def test_graph_replay_is_bit_exact():
+    """EagerTrainer.graph_step (one captured HIP graph per step kind) against the eager path on the same weights and inputs:
+    full steps, the three partition groups, before and after the Adjuster branch switches on — weights, Adam slots and
+    outputs must be bit-identical after every step."""
+    cfg = O.Cfg(init_dim=2, conv_filter=(64, 32, 32, 64, 32), cond_dim=5, noise_dim=11, batch_size=3)
+    W = perturbed(cfg, 5)
+    tr_e, tr_g = build(cfg, W, "bf16"), build(cfg, W, "bf16")
+    steps = [8, 9, 10, 11, 12, 13, 15, 16, 20, 21, 25, 26, 30, 31, 35, 40, 45, 50, 55]   # every kind at least three times (eager, capture, replay)
+    for b in steps:
+        inp = dev_inputs(f32_round(O.make_inputs(cfg, cfg.batch_size, seed=400 + b)))
+        fe, ae, lge, lde, lae = tr_e.train_step_from_inputs(b, inp)
+        fg, ag, lgg, ldg, lag = tr_g.graph_step(b, inp)
+        torch.cuda.synchronize()
+        assert torch.equal(fe, fg) and torch.equal(lge, lgg) and torch.equal(lde, ldg), b
+        assert (ae is None) == (ag is None) and (ae is None or torch.equal(ae, ag)), b
+        for x, y in ((tr_e.store.flat, tr_g.store.flat), (tr_e.store.m, tr_g.store.m), (tr_e.store.v, tr_g.store.v)):
+            assert torch.equal(x, y), b
+    assert len(tr_g._graphs) == 5   # (-1, False), (-1, True) and the three partition groups with the Adjuster on
+
+
 def test_checkpoint_resume_is_bit_exact(tmp_path):
     """Own-format checkpoint with the reference's CONTENT (eager_trainer.py:31-43: the three models, the three
     optimizers' slots and beta powers, status.json epoch): train 3 steps, save, train a 4th; a fresh trainer that
