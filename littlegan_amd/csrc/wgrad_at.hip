@@ -1,0 +1,259 @@
+// All-taps weight gradient of the 5x5 stride-2 layers from the bf16 mirrors (16x16 maps and larger):
+//   dW[ky,kx,cb,cs] = sum_{n,y,x} big[n, 2y+ky-1, 2x+kx-1, cb] * small[n, y, x, cs]       (wgrad_igemm.hip:1-5)
+// The per-tap kernel of wgrad_igemm.hip stages a [pixels x (32..128 + 64..128) channels] operand pair per tap: at the
+// 32/64-channel levels that is 3 KB of staging for two MFMAs, and `big` is pulled through L2 25 times.  Here one block
+// (8 waves, one per CU) owns ALL 25 taps of a 32 (cb) x 64 (cs) slice of dW — 50 accumulator tiles of 32x32 — and walks
+// a list of items (sample, band of R small rows, strip of SW small columns):
+//   * LDS holds the (2R+3) x (2SW+3) halo of `big` (its 32 channels) and the R x SW pixels of `small` (64 channels),
+//     double buffered, staged global -> registers -> LDS behind the MFMAs of the previous item;
+//   * `big` pixels are stored de-interleaved by x parity, `small` split into its two 32-channel halves: every fragment
+//     is then 16 consecutive 64-B rows, which is what ds_read_b64_tr_b16 reads without bank conflicts
+//     (wgrad_igemm.hip:32-36), and a tap is just a byte offset (compile-time per k step, one add per wave for the tap);
+//   * a k step is 16 small pixels of one row; an item has 8 of them.  Wave w owns taps 3w..3w+2 (both cs halves: 6 tiles,
+//     A fragment read once, used twice); tap 24 rotates — wave w runs it on k step w of every item and the 8 partial
+//     tiles are summed through LDS at the end — so every wave issues exactly 50 MFMAs per item.
+//   * output: slab[split][tap][cb][cs] (fp32), reduced in fixed order by slab_reduce4_kernel (deterministic, no atomics).
+#include <stdlib.h>
+#include "lg_common.h"
+
+namespace {
+
+struct WgAtParams {
+  const __bf16* big;    // [B, 2Hm, 2Wm, Cb]
+  const __bf16* small;  // [B, Hm, Wm, Cs]
+  float* slab;          // [nsplit][25][Cb][Cs]
+  int B, Hm, Wm, Cb, Cs;
+  int nuj, nunits;      // units = (Cb/32) x (Cs/64)
+  int items_total, items_per;
+};
+
+template <int SW, int R>
+struct AtCfg {
+  static_assert(R * SW / 16 == 8, "8 k steps per item");
+  static constexpr int NA = SW + 2;               // entries per x-parity array (odd: SW+2 used, even: SW+1)
+  static constexpr int EVEN_OFF = NA * 64;        // odd-x array first
+  static constexpr int ROWP = 2 * NA * 64;        // bytes per big row
+  static constexpr int NBR = 2 * R + 3, NPX = 2 * SW + 3;
+  static constexpr int BIG = NBR * ROWP, SMALL = R * 2 * SW * 64, BUF = BIG + SMALL;
+  static constexpr int NBP = NBR * NPX * 4, NBL = (NBP + 511) / 512;  // 16-B pieces of the halo, per thread
+  static constexpr int NSP = R * SW * 8, NSL = NSP / 512;
+  static_assert(BUF < 65536, "k-step offsets must fit the ds offset field");
+  static_assert(2 * BUF <= 160 * 1024 && 2 * BUF >= 8 * 2 * 4096, "LDS budget; the tap-24 reduction reuses it");
+};
+
+__device__ __forceinline__ bf16x8 rd_tr(const char* p) {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 256));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int SW, int R>
+__global__ __launch_bounds__(512) void wgrad_at_kernel(const WgAtParams p) {
+  using C = AtCfg<SW, R>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bx = lg_xcd_remap(blockIdx.x, gridDim.x);
+  const int unit = bx % p.nunits, split = bx / p.nunits;   // units of one split run together: they share the pixels
+  const int i0 = (unit / p.nuj) * 32, j0 = (unit % p.nuj) * 64;
+  const int it0 = split * p.items_per, it1 = min(it0 + p.items_per, p.items_total);
+  const int nxs = p.Wm / SW, nyb = p.Hm / R;
+  const int Hb = 2 * p.Hm, Wb = 2 * p.Wm;
+
+  u32x4 rbig[C::NBL], rsm[C::NSL];
+  auto load_item = [&](int it) {
+    const int xs = it % nxs, t2 = it / nxs;
+    const int yb = t2 % nyb, n = t2 / nyb;
+    const int gy0 = 2 * yb * R - 1, gx0 = 2 * xs * SW - 1;
+    const __bf16* bbase = p.big + (long long)n * Hb * Wb * p.Cb + i0;
+    const __bf16* sbase = p.small + ((long long)(n * p.Hm + yb * R) * p.Wm + xs * SW) * p.Cs + j0;
+#pragma unroll
+    for (int k = 0; k < C::NBL; ++k) {
+      const int q = tid + k * 512, piece = q & 3, pp = q >> 2;
+      const int row = pp / C::NPX, px = pp - row * C::NPX;
+      const int gy = gy0 + row, gx = gx0 + px;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (q < C::NBP && (unsigned)gy < (unsigned)Hb && (unsigned)gx < (unsigned)Wb)
+        v = *reinterpret_cast<const u32x4*>(bbase + (long long)(gy * Wb + gx) * p.Cb + piece * 8);
+      rbig[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < C::NSL; ++k) {
+      const int q = tid + k * 512, c8 = q & 7, pp = q >> 3;
+      const int yy = pp / SW, px = pp % SW;
+      rsm[k] = *reinterpret_cast<const u32x4*>(sbase + (long long)(yy * p.Wm + px) * p.Cs + c8 * 8);
+    }
+  };
+  auto store_item = [&](char* buf) {
+#pragma unroll
+    for (int k = 0; k < C::NBL; ++k) {
+      const int q = tid + k * 512, piece = q & 3, pp = q >> 2;
+      const int row = pp / C::NPX, px = pp - row * C::NPX;
+      // px 0 <-> big x = 2*X0 - 1 (odd, entry 0); px 1 <-> 2*X0 (even, entry 0); ...
+      if (q < C::NBP) *reinterpret_cast<u32x4*>(buf + row * C::ROWP + ((px & 1) ? C::EVEN_OFF : 0) + (px >> 1) * 64 + piece * 16) = rbig[k];
+    }
+#pragma unroll
+    for (int k = 0; k < C::NSL; ++k) {
+      const int q = tid + k * 512, c8 = q & 7, pp = q >> 3;
+      const int yy = pp / SW, px = pp % SW;
+      *reinterpret_cast<u32x4*>(buf + C::BIG + ((yy * 2 + (c8 >> 2)) * SW + px) * 64 + (c8 & 3) * 16) = rsm[k];
+    }
+  };
+
+  // fragment addressing (wgrad_igemm.hip:195-201): 16-lane group g = (channel half, k half), lane 4q+p -> row q, cols 4p..
+  const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+  const int lanepart = (8 * (g >> 1) + lq) * 64 + (16 * (g & 1) + 4 * lp) * 2;
+  int ab[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int t = 3 * wid + i, ky = t / 5, kx = t - ky * 5;
+    // tap (ky,kx) at small pixel (yy, x): big row 2yy+ky of the halo; x = 2x+kx-1 -> odd array for even kx, entry x + (kx>>1)
+    ab[i] = lanepart + ky * C::ROWP + ((kx & 1) ? C::EVEN_OFF : 0) + (kx >> 1) * 64;
+  }
+  const int a24 = lanepart + 4 * C::ROWP + 2 * 64;
+  const int bb = lanepart + C::BIG;
+
+  f32x16 acc[3][2], acc24[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { acc[i][0][e] = 0.f; acc[i][1][e] = 0.f; }
+    acc24[0][e] = 0.f; acc24[1][e] = 0.f;
+  }
+
+  if (it0 < it1) {
+    load_item(it0);
+    store_item(smem);
+  }
+  __syncthreads();
+  for (int it = it0; it < it1; ++it) {
+    const int cur = (it - it0) & 1;
+    if (it + 1 < it1) load_item(it + 1);
+    const char* sb = smem + cur * C::BUF;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int yy = ks / (SW / 16), xc = ks % (SW / 16);
+      const int koffA = 2 * yy * C::ROWP + xc * 16 * 64;
+      bf16x8 b[2], a[3];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) b[h] = rd_tr(sb + bb + ((yy * 2 + h) * SW + xc * 16) * 64);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) a[i] = rd_tr(sb + ab[i] + koffA);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[h], acc[i][h], 0, 0, 0);
+      if (wid == ks) {
+        const bf16x8 a3 = rd_tr(sb + a24 + koffA);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc24[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b[h], acc24[h], 0, 0, 0);
+      }
+    }
+    if (it + 1 < it1) store_item(smem + (cur ^ 1) * C::BUF);
+    __syncthreads();
+  }
+
+  // slab[split][t][cb][cs]: accumulator register e of lane (r, h) = row (e&3) + 8*(e>>2) + 4h, column r
+  const int r = lane & 31, hh = lane >> 5;
+  float* out = p.slab + (long long)split * 25 * p.Cb * p.Cs;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float* o = out + (long long)(3 * wid + i) * p.Cb * p.Cs + (long long)i0 * p.Cs + j0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[(long long)((e & 3) + 8 * (e >> 2) + 4 * hh) * p.Cs + h * 32 + r] = acc[i][h][e];
+  }
+  // tap 24: 8 partial tile pairs -> LDS [wave][h][e][lane], summed in wave order
+  float* sred = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sred[((wid * 2 + h) * 16 + e) * 64 + lane] = acc24[h][e];
+  __syncthreads();
+  {
+    const int h = tid >> 8, e4 = (tid >> 6) & 3;
+    float* o = out + (long long)24 * p.Cb * p.Cs + (long long)i0 * p.Cs + j0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += sred[((w * 2 + h) * 16 + 4 * e4 + q) * 64 + lane];
+      o[(long long)(q + 8 * e4 + 4 * hh) * p.Cs + h * 32 + r] = s;
+    }
+  }
+}
+
+inline int at_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t pr;
+      if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+    }
+  }
+  return cus;
+}
+
+// 0: not applicable, else the strip width (32 or 16)
+inline int at_shape(int Hm, int Wm, int cb, int cs) {
+  if (cb % 32 || cs % 64 || cb < 32 || cs < 64) return 0;
+  if ((cb / 32) * (cs / 64) > 64) return 0;   // deep levels: few pixels per unit, the per-tap kernel's big tiles do better
+  if (Wm % 32 == 0 && Hm % 4 == 0) return 32;
+  if (Wm % 16 == 0 && Hm % 8 == 0) return 16;
+  return 0;
+}
+
+inline void at_plan(int B, int Hm, int Wm, int cb, int cs, int sw, int* nsplit, int* items_total, int* items_per) {
+  const int R = sw == 32 ? 4 : 8;
+  const int nunits = (cb / 32) * (cs / 64);
+  *items_total = B * (Hm / R) * (Wm / sw);
+  int ns = at_cus() / nunits;
+  if (ns < 1) ns = 1;
+  if (ns > *items_total) ns = *items_total;
+  *items_per = lg_cdiv(*items_total, ns);
+  *nsplit = lg_cdiv(*items_total, *items_per);
+}
+
+}  // namespace
+
+extern "C" size_t lg_wgrad_at_workspace_bytes(int B, int Hm, int Wm, int cb, int cs) {
+  const int sw = at_shape(Hm, Wm, cb, cs);
+  if (!sw) return 0;
+  int ns, tot, per;
+  at_plan(B, Hm, Wm, cb, cs, sw, &ns, &tot, &per);
+  return (size_t)ns * 25 * cb * cs * sizeof(float);
+}
+
+// writes slab[nsplit][25][cb][cs] into `workspace` and *nsplit_out; the caller reduces the slabs (lg_conv_wgrad_m16)
+extern "C" int lg_wgrad_at_try(const void* big16, const void* small16, void* workspace, size_t ws_bytes, int B, int Hm, int Wm,
+                               int cb, int cs, int* nsplit_out, void* stream) {
+  static int off = -1;
+  if (off < 0) off = getenv("LG_NO_WGAT") ? 1 : 0;
+  const int sw = at_shape(Hm, Wm, cb, cs);
+  if (off || !sw || !big16 || !small16 || !nsplit_out) return LG_ERR_UNSUPPORTED;
+  WgAtParams p{};
+  p.big = (const __bf16*)big16; p.small = (const __bf16*)small16; p.slab = (float*)workspace;
+  p.B = B; p.Hm = Hm; p.Wm = Wm; p.Cb = cb; p.Cs = cs;
+  p.nuj = cs / 64; p.nunits = (cb / 32) * (cs / 64);
+  int ns;
+  at_plan(B, Hm, Wm, cb, cs, sw, &ns, &p.items_total, &p.items_per);
+  LG_CHECK_ARG(ws_bytes >= (size_t)ns * 25 * cb * cs * sizeof(float), "lg_wgrad_at: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_at_kernel<32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AtCfg<32, 4>::BUF);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_at_kernel<16, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * AtCfg<16, 8>::BUF);
+    attr = true;
+  }
+  constexpr int LDS32 = 2 * AtCfg<32, 4>::BUF, LDS16 = 2 * AtCfg<16, 8>::BUF;
+  if (sw == 32) hipLaunchKernelGGL((wgrad_at_kernel<32, 4>), dim3(p.nunits * ns), dim3(512), LDS32, st, p);
+  else hipLaunchKernelGGL((wgrad_at_kernel<16, 8>), dim3(p.nunits * ns), dim3(512), LDS16, st, p);
+  LG_CHECK_LAUNCH("lg_wgrad_at");
+  *nsplit_out = ns;
+  return LG_OK;
+}

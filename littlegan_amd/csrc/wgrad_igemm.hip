@@ -399,11 +399,15 @@ inline int pick_nsplit(int tiles, int M, int KP, int slots) {
 extern "C" size_t lg_n3_wgrad_workspace_bytes(int B, int H, int W, int Cs);
 extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void* small16, float* dw, void* workspace,
                                size_t ws_bytes, int B, int H, int W, int Cs, int s, int pad, int accumulate, void* stream);
+extern "C" size_t lg_wgrad_at_workspace_bytes(int B, int Hm, int Wm, int cb, int cs);
+extern "C" int lg_wgrad_at_try(const void* big16, const void* small16, void* workspace, size_t ws_bytes, int B, int Hm, int Wm,
+                               int cb, int cs, int* nsplit_out, void* stream);
 static size_t wgrad_ws_generic(int B, int Hm, int Wm, int cb, int cs, int dtype);
 
 extern "C" size_t lg_wgrad_workspace_bytes(int B, int Hm, int Wm, int cb, int cs, int dtype) {
   size_t g = wgrad_ws_generic(B, Hm, Wm, cb, cs, dtype);
   if (cb == 3) { const size_t n = lg_n3_wgrad_workspace_bytes(B, Hm, Wm, cs); if (n > g) g = n; }
+  else if (dtype == LG_DT_BF16) { const size_t n = lg_wgrad_at_workspace_bytes(B, Hm, Wm, cb, cs); if (n > g) g = n; }
   return g;
 }
 
@@ -447,6 +451,19 @@ extern "C" int lg_conv_wgrad_m16(const float* big, const void* big16, const floa
     if (rc != LG_ERR_UNSUPPORTED) return rc;
   }
   LG_CHECK_ARG((big && small) || (cb != 3 && big16 && small16), "lg_conv_wgrad: this shape needs the fp32 operands");
+  if (cb != 3 && dtype == LG_DT_BF16 && big16 && small16) {  // all-taps kernel (wgrad_at.hip) on the 16x16 maps and larger
+    int ns_at = 0;
+    const int rc = lg_wgrad_at_try(big16, small16, workspace, ws_bytes, B, Hm, Wm, cb, cs, &ns_at, stream);
+    if (rc == LG_OK) {
+      const long long n4 = 25LL * cb * cs / 4;
+      const int rb4 = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+      hipLaunchKernelGGL(slab_reduce4_kernel, dim3(rb4), dim3(256), 0, (hipStream_t)stream, (const f32x4*)workspace, (f32x4*)dw,
+                         ns_at, n4, accumulate);
+      LG_CHECK_LAUNCH("lg_conv_wgrad(reduce)");
+      return LG_OK;
+    }
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+  }
   const bool patch = cb == 3;
   const bool bf16 = dtype == LG_DT_BF16 && !patch;  // patch layers stay on the exact f32 MFMA
   const int KP = bf16 ? 64 : 32;

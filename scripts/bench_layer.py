@@ -10,7 +10,8 @@ LAYERS = [  # name, kind, Hs, cb, cs
     ("convT1 fwd 8->16", "up", 8, 256, 384), ("convT2 fwd 16->32", "up", 16, 128, 256), ("convT3 fwd 32->64", "up", 32, 64, 128),
     ("convT4 fwd 64->128", "up", 64, 32, 64), ("conv2 fwd 64->32", "down", 32, 64, 128), ("conv3 fwd 32->16", "down", 16, 128, 256),
     ("conv4 fwd 16->8", "down", 8, 256, 384), ("final s1t 128", "s1t", 128, 3, 32), ("conv1 dgrad 64->128", "up", 64, 3, 64),
-    ("wgrad 16/32 (128,256)", "wgrad", 16, 128, 256), ("wgrad 64/128 (32,64)", "wgrad", 64, 32, 64),
+    ("wgrad 16/32 (128,256)", "wgrad", 16, 128, 256), ("wgrad 32/64 (64,128)", "wgrad", 32, 64, 128), ("wgrad 64/128 (32,64)", "wgrad", 64, 32, 64),
+    ("wgrad 8/16 (256,384)", "wgrad", 8, 256, 384),
     ("convT4 dgrad 128->64", "ddown", 64, 32, 64), ("convT3 dgrad 64->32", "ddown", 32, 64, 128), ("convT2 dgrad 32->16", "ddown", 16, 128, 256),
     ("conv2 dgrad 32->64", "dup", 32, 64, 128), ("conv3 dgrad 16->32", "dup", 16, 128, 256), ("conv4 dgrad 8->16", "dup", 8, 256, 384),
 ]
@@ -52,6 +53,9 @@ for name, kind, Hs, cb, cs in LAYERS:
     else:
         dw = torch.empty(5, 5, cb, cs, device="cuda")
         fn = lambda: ops.conv2d_s2_wgrad(big, small, dw, False, dt)
+        if M16:
+            b16, s16 = big.to(torch.bfloat16), small.to(torch.bfloat16)
+            fn = lambda: ops.conv2d_s2_wgrad(None, None, dw, False, dt, x16=b16, dy16=s16)
     for _ in range(3):
         fn()
     torch.cuda.synchronize()

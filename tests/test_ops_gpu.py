@@ -293,7 +293,9 @@ def test_bf16_mirror_operands_are_bit_identical(ops, case):
         ops.conv2d_s2_wgrad(xd, dyd, dw0, False, 1)
         ops.conv2d_s2_wgrad(xd, dyd, dw1, False, 1, x16=x16, dy16=dy16)
         zz = y1
-    assert torch.equal(y0, y1) and torch.equal(dx0, dx1) and torch.equal(dw0, dw1)
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    # the mirrors may select the all-taps weight-gradient kernel (csrc/wgrad_at.hip): same bf16 products, another fp32 summation order
+    assert torch.equal(dw0, dw1) or rel(dw1, dw0.cpu().numpy()) < 2e-6
     if st is not None:  # fused moments == moments of the produced tensor
         zf = zz.double().reshape(B, -1)
         assert rel(st[:, 0], zf.mean(1).cpu().numpy()) < 1e-6 and rel(st[:, 1], zf.std(1, unbiased=False).cpu().numpy()) < 1e-6
