@@ -276,20 +276,37 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
       if constexpr (STATS) sstat[tid] = f32x2{s1v[0] + s1v[1], s2v[0] + s2v[1]};  // reduced by ONE wave per tile behind the barrier
     }
     U3_STAMP();  // staged
-    __syncthreads();  // every class of the tile(s) is staged, every halo read is done
-    U3_STAMP();  // barrier 1 passed
-
-    if (more) commit(hv);
     int tns[C::NT], ty0s[C::NT], tx0s[C::NT];
     bool tlive[C::NT];
 #pragma unroll
     for (int t = 0; t < C::NT; ++t) tlive[t] = tile_of(s, t, tns[t], ty0s[t], tx0s[t]);
+    constexpr int PPO = C::CROW / 16;                 // pieces per output pixel (8 | 4)
+    constexpr int TOT = C::NT * C::OPX * PPO;         // 4096 pieces per step either way
+    // FUSE: the z pieces this thread will meet in the row sweep are requested NOW — the accumulators are dead (staged), and
+    // the loads land behind the barrier and the halo commit instead of in front of every use
+    u32x4 zq[FUSE ? TOT / 512 : 1];
+    (void)zq;
+    if constexpr (FUSE) {
+#pragma unroll
+      for (int q8 = 0; q8 < TOT / 512; ++q8) {
+        const int q = tid + q8 * 512;
+        const int t = q / (C::OPX * PPO), rem = q - t * (C::OPX * PPO);
+        const int o = rem / PPO, j = rem - o * PPO;
+        const bool t1 = C::NT == 2 && t != 0;
+        const int tn_ = t1 ? tns[C::NT - 1] : tns[0], ty0 = t1 ? ty0s[C::NT - 1] : ty0s[0], tx0 = t1 ? tx0s[C::NT - 1] : tx0s[0];
+        const bool tl = t1 ? tlive[C::NT - 1] : tlive[0];
+        const long long goff = ((long long)(tn_ * 2 * p.Hs + 2 * ty0 + (o >> 5)) * (2 * p.Ws) + 2 * tx0 + (o & 31)) * N + j * 8;
+        zq[q8] = tl ? *reinterpret_cast<const u32x4*>(p.nf.z + goff) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+    __syncthreads();  // every class of the tile(s) is staged, every halo read is done
+    U3_STAMP();  // barrier 1 passed
+
+    if (more) commit(hv);
     // ---- whole output rows out: 16 rows x (32 pixels x N channels) contiguous, 16 B per lane ------------------------------
     {
       float nf1 = 0.f, nf2 = 0.f;
       (void)nf1; (void)nf2;
-      constexpr int PPO = C::CROW / 16;                 // pieces per output pixel (8 | 4)
-      constexpr int TOT = C::NT * C::OPX * PPO;         // 4096 pieces per step either way
 #pragma unroll
       for (int q8 = 0; q8 < TOT / 512; ++q8) {
         const int q = tid + q8 * 512;
@@ -303,9 +320,8 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
         if (tl) *reinterpret_cast<u32x4*>(p.out + goff) = v;
         if constexpr (FUSE) {
           if (tl) {
-            const u32x4 zq = *reinterpret_cast<const u32x4*>(p.nf.z + goff);
             const float* sp = p.nf.stats + (long long)tn_ * 8;
-            lg_nf_accum(v, zq, sp[0], sp[4], sp[2], sp[3], p.nf.alpha, nf1, nf2);
+            lg_nf_accum(v, zq[q8], sp[0], sp[4], sp[2], sp[3], p.nf.alpha, nf1, nf2);
           }
         }
       }

@@ -15,6 +15,7 @@ LAYERS = [  # name, kind, Hs, cb, cs
     ("convT4 dgrad 128->64", "ddown", 64, 32, 64), ("convT3 dgrad 64->32", "ddown", 32, 64, 128), ("convT2 dgrad 32->16", "ddown", 16, 128, 256),
     ("conv2 dgrad 32->64", "dup", 32, 64, 128), ("conv3 dgrad 16->32", "dup", 16, 128, 256), ("conv4 dgrad 8->16", "dup", 8, 256, 384),
 ]
+FUSE = os.environ.get("LG_FUSE", "0") == "1"  # data-gradient cases: with the norm-backward sums of the layer below in the epilogue
 M16 = os.environ.get("LG_M16", "1") == "1" and dt == 1  # production bf16 path: sources read from their bf16 mirrors
 gm, bt = torch.ones(1, device="cuda"), torch.zeros(1, device="cuda")
 sel = sys.argv[1:] or None
@@ -41,9 +42,17 @@ for name, kind, Hs, cb, cs in LAYERS:
     elif kind == "ddown":  # data gradient of a transposed conv (DOWN form): dz [B,2Hs,2Hs,cb] bf16 -> g [B,Hs,Hs,cs] bf16
         d16 = big.to(torch.bfloat16)
         fn = lambda: ops.convT_s2_dgrad(None, pack, cs, dt, dy16=d16, out_bf16=True)
+        if FUSE:
+            zf = small.to(torch.bfloat16)
+            stf = ops.instnorm_stats(small, gm, bt, 0, 0.3)
+            fn = lambda: ops.convT_s2_dgrad(None, pack, cs, dt, dy16=d16, out_bf16=True, fuse=(zf, stf, 0.3))
     elif kind == "dup":    # data gradient of a conv (UP form): dz [B,Hs,Hs,cs] bf16 -> g [B,2Hs,2Hs,cb] bf16
         d16 = small.to(torch.bfloat16)
         fn = lambda: ops.conv2d_s2_dgrad(None, pack, cb, dt, dy16=d16, out_bf16=True)
+        if FUSE:
+            zf = big.to(torch.bfloat16)
+            stf = ops.instnorm_stats(big, gm, bt, 0, 0.3)
+            fn = lambda: ops.conv2d_s2_dgrad(None, pack, cb, dt, dy16=d16, out_bf16=True, fuse=(zf, stf, 0.3))
     elif kind == "s1t":
         out = torch.empty(B, Hs, Hs, cb, device="cuda")
         fn = lambda: ops.convT_s1_tanh_fwd(small, pack, bias_b, cb, dt, out=out)
