@@ -104,6 +104,12 @@ int lg_n3_m16_supported(int H, int W, int cb, int cs, int dtype);
  * gradient is written as bf16 there instead of fp32 to dx (give at most one of dx, dx16) */
 int lg_convT_s1_tanh_fwd_m16(const float* x, const void* x16, const void* pack, const float* bias, float* y, int B, int H,
                              int W, int cb, int cs, int dtype, void* stream);
+/* the same layer fed with the RAW bf16 conv output z16 of the level below and its statistics records (stats [B][8]):
+ * InstanceNormalization + LeakyReLU(alpha) are applied while the input is staged, the normalised tensor is never written
+ * (/root/reference/model.py:46-50 feeding model.py:86-87).  LG_ERR_UNSUPPORTED unless ..._z16_supported. */
+int lg_convT_s1_tanh_fwd_z16_supported(int H, int W, int cb, int cs, int dtype);
+int lg_convT_s1_tanh_fwd_z16(const void* z16, const float* stats, float alpha, const void* pack, const float* bias, float* y,
+                             int B, int H, int W, int cb, int cs, int dtype, void* stream);
 int lg_convT_s1_tanh_bwd_m16(const float* x, const void* x16, const float* dpre, const void* pack, float* dx, void* dx16,
                              float* dw, float* db, void* workspace, size_t ws_bytes, int B, int H, int W, int cb, int cs,
                              int accumulate, int dtype, void* stream);

@@ -37,6 +37,9 @@ extern "C" int lg_n3_conv1_fwd_p16_try(const float* img, const float* w, const f
                                        int W, int N, void* spart, size_t spart_bytes, int* nparts, void* stream);
 extern "C" int lg_n3_s1_dgrad_p16_try(const float* dpre, const float* w, float* dx, void* dx16, int B, int H, int W, int N,
                                       void* stream);
+extern "C" int lg_n3_rows_supported(int H, int W, int C);
+extern "C" int lg_n3_s1t_fwd_rows_try(const void* x16, const float* stats, float alpha, const float* w, const float* bias, float* y,
+                                      int B, int H, int W, int C, void* stream);
 static bool n3_enabled() {
   static int v = -1;
   if (v < 0) v = getenv("LG_NO_N3") ? 0 : 1;  // A/B switch
@@ -225,11 +228,28 @@ extern "C" int lg_n3_m16_supported(int H, int W, int cb, int cs, int dtype) {
 extern "C" int lg_convT_s1_tanh_fwd_m16(const float* x, const void* x16, const void* pack, const float* bias, float* y,
                                         int B, int H, int W, int cb, int cs, int dtype, void* stream) {
   if (x16 && lg_n3_m16_supported(H, W, cb, cs, dtype)) {
-    const int rc = lg_n3_s1t_fwd_p16_try(x16, raw_pack(pack, cb, cs, dtype), bias, y, B, H, W, cs, stream);
+    int rc = lg_n3_s1t_fwd_rows_try(x16, nullptr, 0.f, raw_pack(pack, cb, cs, dtype), bias, y, B, H, W, cs, stream);
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+    rc = lg_n3_s1t_fwd_p16_try(x16, raw_pack(pack, cb, cs, dtype), bias, y, B, H, W, cs, stream);
     if (rc != LG_ERR_UNSUPPORTED) return rc;
   }
   LG_CHECK_ARG(x, "lg_convT_s1_tanh_fwd_m16: this shape needs the fp32 input (see lg_n3_m16_supported)");
   return lg_convT_s1_tanh_fwd(x, pack, bias, y, B, H, W, cb, cs, dtype, stream);
+}
+
+// 1 if lg_convT_s1_tanh_fwd_z16 runs this shape (InstanceNorm + LeakyReLU of the input applied while it is staged)
+extern "C" int lg_convT_s1_tanh_fwd_z16_supported(int H, int W, int cb, int cs, int dtype) {
+  return (dtype == LG_DT_BF16 && cb == 3 && n3_enabled() && !getenv("LG_NO_ROWS") && lg_n3_rows_supported(H, W, cs)) ? 1 : 0;
+}
+
+// y = tanh(convT_s1(h) + bias) with h = bf16(LeakyReLU_alpha(a*((z - mu) - mu_lo) + beta)) formed on the fly from the raw
+// bf16 conv output z16 [B,H,W,cs] and its statistics records stats [B][8] (lg_instnorm_leaky_stats layout): the
+// normalised activation is never written.  LG_ERR_UNSUPPORTED outside lg_convT_s1_tanh_fwd_z16_supported.
+extern "C" int lg_convT_s1_tanh_fwd_z16(const void* z16, const float* stats, float alpha, const void* pack, const float* bias,
+                                        float* y, int B, int H, int W, int cb, int cs, int dtype, void* stream) {
+  LG_CHECK_ARG(z16 && stats && pack && bias && y, "lg_convT_s1_tanh_fwd_z16: null pointer");
+  if (!lg_convT_s1_tanh_fwd_z16_supported(H, W, cb, cs, dtype)) return LG_ERR_UNSUPPORTED;
+  return lg_n3_s1t_fwd_rows_try(z16, stats, alpha, raw_pack(pack, cb, cs, dtype), bias, y, B, H, W, cs, stream);
 }
 
 extern "C" int lg_convT_s1_tanh_fwd(const float* x, const void* pack, const float* bias, float* y, int B, int H, int W,

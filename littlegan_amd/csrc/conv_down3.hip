@@ -264,8 +264,19 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
         const double w1 = lg_wave_sum_d((double)s1v[0] + (double)s1v[1]), w2 = lg_wave_sum_d((double)s2v[0] + (double)s2v[1]);
         if (lane == 0) { sred[(k & 1) * 8 + wid] = w1; sred[(k & 1) * 8 + 4 + wid] = w2; }
       }
-      __syncthreads();  // tile complete in LDS (and the wave sums)
       const long long obase = ((long long)(cur.n * p.Hm + cur.y0) * p.Wm + cur.x0) * p.N + cur.tn * 128;
+      // FUSE: the z pieces of the row sweep are requested now — the accumulators are dead (staged), the loads land behind
+      // the barrier instead of in front of every use
+      u32x4 zq[FUSE ? 8 : 1];
+      (void)zq;
+      if constexpr (FUSE) {
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) {
+          const int piece = tid + q8 * 256, row = piece >> 4, j = piece & 15;
+          zq[q8] = *reinterpret_cast<const u32x4*>(p.nf.z + obase + ((long long)(row >> 4) * p.Wm + (row & 15)) * p.N + j * 8);
+        }
+      }
+      __syncthreads();  // tile complete in LDS (and the wave sums)
       float nf1 = 0.f, nf2 = 0.f;
       (void)nf1; (void)nf2;
 #pragma unroll
@@ -275,9 +286,8 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
         const long long goff = obase + ((long long)(row >> 4) * p.Wm + (row & 15)) * p.N + j * 8;
         *reinterpret_cast<u32x4*>(p.out + goff) = v;
         if constexpr (FUSE) {
-          const u32x4 zq = *reinterpret_cast<const u32x4*>(p.nf.z + goff);
           const float* sp = p.nf.stats + (long long)cur.n * 8;
-          lg_nf_accum(v, zq, sp[0], sp[4], sp[2], sp[3], p.nf.alpha, nf1, nf2);
+          lg_nf_accum(v, zq[q8], sp[0], sp[4], sp[2], sp[3], p.nf.alpha, nf1, nf2);
         }
       }
       if constexpr (FUSE) {

@@ -1,0 +1,210 @@
+// Final generator layer on the bf16 activation path, as a row-sliding product with NO block barrier and no P round trip:
+//   y[n,y,x,co] = tanh(b[co] + sum_{ky,kx,c} h[n, y+2-ky, x+2-kx, c] * W[ky][kx][co][c])     /root/reference/model.py:86-87,104
+// One wave owns a strip of 16 output columns and walks DOWN the input rows, holding FIVE output rows in flight
+// (5 accumulator tiles of 16 pixels x 16 columns, columns 0..2 = co).  Input row yy is staged once (20 pixels x 32
+// channels), its five kx-shifted A fragments are read with ds_read_b128, and 25 v_mfma_f32_16x16x32_bf16 add its
+// contribution to the five output rows y = yy - 2 + ky it touches (B fragment (ky,kx) = W[ky][kx][co][c], resident in
+// registers for the whole strip).  After that the oldest output row is complete: its 48 values go through 192 B of
+// wave-private LDS to become one contiguous 192-B store after bias + tanh, and its accumulator restarts as the newest row.
+// 13 of the 16 MFMA columns are padding — deliberately: the matrix pipe is otherwise idle in this HBM-bound layer and the
+// alternative (15 real columns (ky,co) + a per-lane select / cross-lane shift-sum) costs 3x the VALU issue slots, which
+// is what bounded the first version of this kernel.  Per row segment: 1.25 KB from L2/HBM (fetched once, 16 B per lane,
+// coalesced, two rows ahead), 6.25 KB of LDS traffic, 25 MFMAs (400 issue cycles), ~50 other instructions.
+// NORM: the input is the raw bf16 conv output z of the last decoder level and h = bf16(leaky(a*((z-mu)-mu_lo)+beta)) is
+// formed while staging (same arithmetic, same rounding as apply16_kernel in norm.hip) — the stand-alone apply pass and the
+// h16 tensor of the 128x128x32 map disappear.
+#include <stdlib.h>
+#include <type_traits>
+#include "lg_common.h"
+
+namespace {
+
+struct RowsNormIn { const float* stats; float alpha; };
+
+__device__ __forceinline__ bf16x8 cvt8w(const float* p) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  bf16x8 v;
+  v[0] = (__bf16)a[0]; v[1] = (__bf16)a[1]; v[2] = (__bf16)a[2]; v[3] = (__bf16)a[3];
+  v[4] = (__bf16)b[0]; v[5] = (__bf16)b[1]; v[6] = (__bf16)b[2]; v[7] = (__bf16)b[3];
+  return v;
+}
+
+// 8 bf16 z -> 8 bf16 h, exactly apply16_kernel (norm.hip): t = a*((z - mu) - mul) + b; leaky; RNE
+__device__ __forceinline__ u32x4 norm8(const u32x4 z8, float mu, float mul, float a, float b, float alpha) {
+  u32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float t0 = __builtin_bit_cast(float, z8[k] << 16), t1 = __builtin_bit_cast(float, z8[k] & 0xffff0000u);
+    t0 = a * ((t0 - mu) - mul) + b; t1 = a * ((t1 - mu) - mul) + b;
+    t0 = lg_leaky(t0, alpha); t1 = lg_leaky(t1, alpha);
+    const __bf16 h0 = (__bf16)t0, h1 = (__bf16)t1;
+    o[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+  }
+  return o;
+}
+
+template <int C, bool NORM>
+__global__ __launch_bounds__(256) void s1t_fwd_rows_kernel(const __bf16* __restrict__ x16, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int B, int H,
+                                                           int W, int RB, const RowsNormIn ni) {
+  static_assert(C == 32, "one K = 32 MFMA step per tap; 25 B fragments of 4 registers stay resident");
+  constexpr int NPC = C / 8, NP = 20 * NPC, NL = (NP + 63) / 64, FSH = 2;
+  constexpr int ROWB = 20 * C * 2;                 // staged row
+  constexpr unsigned OOB = 0x40000000u;            // buffer offsets >= this are out of range for any image here (< 1 GiB)
+  // per wave: the staged row, then 64 x 16 B of dump slots (lanes with nothing to stage write there: the steady-state loop
+  // has NO branch — a branch makes the compiler wait for ALL outstanding loads at the join, i.e. one HBM latency per row)
+  __shared__ __attribute__((aligned(16))) char srow[4][2 * ROWB + 64 * 16];  // two row buffers: row s+1 is staged under the MFMAs of row s
+  __shared__ __attribute__((aligned(16))) float sout[4][48 + 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int nsx = (W + 63) / 64, nry = (H + RB - 1) / RB;
+  int bb = blockIdx.x;
+  const int sx = bb % nsx; bb /= nsx;
+  const int ry = bb % nry, n = bb / nry;
+  const int x0 = sx * 64 + wid * 16;
+  if (x0 >= W) return;  // no block barrier anywhere below
+  const int ya = ry * RB, yb = min(ya + RB, H), cnt = yb - ya + 4;
+  char* my = srow[wid];
+  float* mo = sout[wid];
+
+  // B fragment (ky,kx): column nn = co (3..15 = padding), k = channel: lane l holds B[k = 8(l>>4) + j][col l&15]
+  bf16x8 bw[5][5];
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx)
+      bw[ky][kx] = r < 3 ? cvt8w(w + (long long)((ky * 5 + kx) * 3 + r) * C + g * 8) : __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+  const float bl = bias[lane % 3];
+  float mu = 0.f, mul = 0.f, na = 1.f, nb = 0.f;
+  if constexpr (NORM) {
+    const float* sp = ni.stats + (long long)n * 8;
+    mu = sp[0]; na = sp[2]; nb = sp[3]; mul = sp[4];
+  }
+  // staging geometry: piece q = lane + 64k of the 20-pixel row -> pixel p, 16-B piece j.  The row is fetched with raw
+  // buffer loads over this image (num_records = its bytes): pieces left / right of the image and rows above / below it
+  // get an out-of-range offset and come back as zeros.
+  unsigned goff[NL];
+  int loff[NL], lbuf[NL];  // lbuf: distance to the same slot of the second row buffer (0 for a dump slot)
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int q = lane + 64 * k, p = q / NPC, j = q - p * NPC, xx = x0 - 2 + p;
+    goff[k] = (q < NP && (unsigned)xx < (unsigned)W) ? (unsigned)(xx * C + j * 8) * 2u : OOB;
+    loff[k] = q < NP ? p * C * 2 + (((j ^ (p >> FSH)) & (NPC - 1)) << 4) : 2 * ROWB + lane * 16;
+    lbuf[k] = q < NP ? ROWB : 0;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(x16 + (long long)n * H * W * C), 0, H * W * C * 2, 0x00027000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(y + (long long)n * H * W * 3, 0, H * W * 3 * 4, 0x00027000);
+  const int rowbytes = W * C * 2;
+  u32x4 rg[2][NL];
+  // branch-free scalar select (a ?: here becomes a scalar branch, and a branch is a scheduling barrier for the MFMA stream)
+  auto sel = [](bool c, unsigned a, unsigned b) { const unsigned m = 0u - (unsigned)c; return (a & m) | (b & ~m); };
+  auto fetch = [&](int s, u32x4 (&dst)[NL]) {
+    const int yy = ya - 2 + s;
+    const unsigned ro = sel((unsigned)yy < (unsigned)H && s < cnt, (unsigned)(yy * rowbytes), OOB);
+#pragma unroll
+    for (int k = 0; k < NL; ++k) dst[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[k] + ro, 0, 0);
+  };
+  // A fragment of shift kx: lane (r, g) needs pixel p = r + 4 - kx, channels 8g .. 8g+7 (piece g)
+  int aoff[5];
+#pragma unroll
+  for (int kx = 0; kx < 5; ++kx) {
+    const int p = r + 4 - kx;
+    aoff[kx] = p * C * 2 + (((g ^ (p >> FSH)) & (NPC - 1)) << 4);
+  }
+  // output staging: lane (r < 3, g) drops row x = 4g + e at float (4g + e)*3 + r; other lanes into their dump slot
+  const int wofs = r < 3 ? (4 * g * 3 + r) : 48 + lane;
+  const int wstep = r < 3 ? 3 : 0;
+  const unsigned yofs = lane < 48 ? (unsigned)((x0 * 3 + lane) * 4) : OOB;
+
+  // the five output rows in flight are five NAMED tiles handed to a step by reference in rotated order (an accumulator
+  // ARRAY indexed by the step would become a runtime-indexed private array, i.e. scratch memory)
+  f32x4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0, T3 = T0, T4 = T0;
+
+  // row s: registers -> (norm) -> wave-private LDS buffer s & 1, then its five A fragments
+  bf16x8 af[2][5];
+  auto stage = [&](auto p_c, int s) {
+    constexpr int P = decltype(p_c)::value;
+    const int yy = ya - 2 + s;
+    const bool rok = (unsigned)yy < (unsigned)H && s < cnt;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      u32x4 v = rg[P][k];
+      if constexpr (NORM) {
+        const u32x4 t = norm8(v, mu, mul, na, nb, ni.alpha);
+        const bool ok = rok && goff[k] != OOB;  // padding stays zero (it is h that is zero-padded, not z)
+        v = u32x4{ok ? t[0] : 0u, ok ? t[1] : 0u, ok ? t[2] : 0u, ok ? t[3] : 0u};
+      }
+      *reinterpret_cast<u32x4*>(my + loff[k] + lbuf[k] * P) = v;
+    }
+    fetch(s + 2, rg[P]);
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) af[P][kx] = *reinterpret_cast<const bf16x8*>(my + P * ROWB + aoff[kx]);
+  };
+  // input row s (yy = ya - 2 + s) adds to the output rows yy - 2 + ky: O0 (ky = 0) is completed by it, O4 (ky = 4) starts.
+  // Row s + 1 is staged and its fragments requested BEFORE the 25 MFMAs of row s, so the LDS round trip hides under them.
+  auto step = [&](auto p_c, int s, f32x4& O0, f32x4& O1, f32x4& O2, f32x4& O3, f32x4& O4) {
+    constexpr int P = decltype(p_c)::value;
+    stage(std::integral_constant<int, P ^ 1>{}, s + 1);
+    O4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) {  // five independent accumulation chains
+      O0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P][kx], bw[0][kx], O0, 0, 0, 0);
+      O1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P][kx], bw[1][kx], O1, 0, 0, 0);
+      O2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P][kx], bw[2][kx], O2, 0, 0, 0);
+      O3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P][kx], bw[3][kx], O3, 0, 0, 0);
+      O4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P][kx], bw[4][kx], O4, 0, 0, 0);
+    }
+    // output row ya + s - 4 is complete (when 4 <= s < cnt; otherwise the store offset is out of range and dropped):
+    // C layout row (= x) 4g + e, column r (= co for r < 3)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mo[wofs + e * wstep] = O0[e];
+    {
+      // tanh(v) = 1 - 2 / (1 + e^{2v}): |error| < 2e-7 absolute over the whole range (e^{2v} -> inf / 0 saturate to +-1)
+      const float v = mo[lane] + bl;
+      const float ex = __builtin_amdgcn_exp2f(v * 2.885390082f);
+      const float o = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + ex);
+      const unsigned yo = sel(s >= 4 && s < cnt, (unsigned)((ya + s - 4) * W * 12), OOB);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), yrsrc, yofs + yo, 0, 0);
+    }
+  };
+
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  fetch(0, rg[0]);
+  fetch(1, rg[1]);
+  stage(P0{}, 0);
+  for (int s0 = 0; s0 < cnt; s0 += 10) {  // whole groups of ten; steps past cnt fetch nothing and store nothing
+    step(P0{}, s0 + 0, T0, T1, T2, T3, T4);
+    step(P1{}, s0 + 1, T1, T2, T3, T4, T0);
+    step(P0{}, s0 + 2, T2, T3, T4, T0, T1);
+    step(P1{}, s0 + 3, T3, T4, T0, T1, T2);
+    step(P0{}, s0 + 4, T4, T0, T1, T2, T3);
+    step(P1{}, s0 + 5, T0, T1, T2, T3, T4);
+    step(P0{}, s0 + 6, T1, T2, T3, T4, T0);
+    step(P1{}, s0 + 7, T2, T3, T4, T0, T1);
+    step(P0{}, s0 + 8, T3, T4, T0, T1, T2);
+    step(P1{}, s0 + 9, T4, T0, T1, T2, T3);
+  }
+}
+
+}  // namespace
+
+extern "C" int lg_n3_rows_supported(int H, int W, int C) { return (W % 16 == 0 && H >= 1 && C == 32) ? 1 : 0; }
+
+// x16: the bf16 input h [B,H,W,C]; or, with stats != null, the raw bf16 conv output z of the level below, normalised +
+// LeakyReLU(alpha)'d on the fly from its statistics records [B][8] (norm.hip)
+extern "C" int lg_n3_s1t_fwd_rows_try(const void* x16, const float* stats, float alpha, const float* w, const float* bias, float* y,
+                                      int B, int H, int W, int C, void* stream) {
+  static int off = -1;
+  if (off < 0) off = getenv("LG_NO_ROWS") ? 1 : 0;
+  if (off || !lg_n3_rows_supported(H, W, C) || !x16 || !w || !bias || !y) return LG_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int RB = H <= 64 ? H : 64;
+  const dim3 grid(B * ((W + 63) / 64) * ((H + RB - 1) / RB));
+  const RowsNormIn ni{stats, alpha};
+  const __bf16* x = (const __bf16*)x16;
+  if (stats) hipLaunchKernelGGL((s1t_fwd_rows_kernel<32, true>), grid, dim3(256), 0, st, x, w, bias, y, B, H, W, RB, ni);
+  else hipLaunchKernelGGL((s1t_fwd_rows_kernel<32, false>), grid, dim3(256), 0, st, x, w, bias, y, B, H, W, RB, ni);
+  LG_CHECK_LAUNCH("lg_n3_s1t_fwd_rows");
+  return LG_OK;
+}

@@ -283,6 +283,27 @@ def convT_s1_tanh_fwd(x, pack, bias, cb, dtype, out=None, x16=None):
     return out
 
 
+def convT_s1_tanh_fwd_z16_supported(H, W, cb, cs, dtype):
+    return bool(_lib.load().lg_convT_s1_tanh_fwd_z16_supported(H, W, cb, cs, dtype))
+
+
+def convT_s1_tanh_fwd_z16(z16, stats, alpha, pack, bias, cb, dtype, out=None):
+    """The final layer fed with the RAW bf16 conv output z16 [B,H,W,cs] of the last decoder level and its statistics:
+    InstanceNorm + LeakyReLU(alpha) happen while the kernel stages its input, the normalised map is never written."""
+    B, H, W, cs = z16.shape
+    _chk16(z16, z16, "z16")
+    _chk(stats, (B, NSTAT), "stats")
+    if out is None:
+        out = torch.empty(B, H, W, cb, dtype=torch.float32, device=z16.device)
+    _chk(out, (B, H, W, cb), "out")
+    _chk(bias, (cb,), "bias")
+    e0 = _pb()
+    check(_lib.load().lg_convT_s1_tanh_fwd_z16(_p(z16), _p(stats), float(alpha), _p(pack), _p(bias), _p(out), B, H, W, cb, cs,
+                                               dtype, _stream()), "lg_convT_s1_tanh_fwd_z16")
+    _pe(e0, "conv_igemm_s1t_n3", 50.0 * B * H * W * cb * cs)
+    return out
+
+
 def convT_s1_tanh_bwd(x, dpre, pack, cs, dtype, dx=None, dw=None, db=None, accumulate=False, x16=None, dx16=None, fuse=None):
     """x16: bf16 mirror of x for the weight gradient; dx16: bf16 tensor that receives the data gradient instead of dx.
     fuse = (z16, stats, alpha) (with dx16): also the first-pass sums of the norm backward dx16 feeds -> returns

@@ -59,6 +59,9 @@ for name, kind, Hs, cb, cs in LAYERS:
         if M16:
             s16 = small.to(torch.bfloat16)
             fn = lambda: ops.convT_s1_tanh_fwd(None, pack, bias_b, cb, dt, out=out, x16=s16)
+            if os.environ.get("LG_Z16", "0") == "1":  # InstanceNorm + LeakyReLU applied while staging the raw conv output
+                stz = ops.instnorm_stats(small, gm, bt, 0, 0.3)
+                fn = lambda: ops.convT_s1_tanh_fwd_z16(s16, stz, 0.3, pack, bias_b, cb, dt, out=out)
     else:
         dw = torch.empty(5, 5, cb, cs, device="cuda")
         fn = lambda: ops.conv2d_s2_wgrad(big, small, dw, False, dt)

@@ -361,6 +361,30 @@ def test_n3_tap_product_kernels_from_bf16_mirror(ops, case):
     assert rel(dw1, O.conv2d_bwd(_bf16_round(x3), w1, dzr, 2)[1]) < 3e-5
 
 
+@pytest.mark.parametrize("case", [(2, 16, 16, 32), (1, 80, 48, 32), (1, 144, 16, 32)])
+def test_final_layer_normalises_while_staging(ops, case):
+    """lg_convT_s1_tanh_fwd_z16 (n3_rows.hip): InstanceNorm + LeakyReLU applied to the raw bf16 conv output while the final
+    layer stages it == the stand-alone apply pass followed by the same layer, bit for bit; and both match the oracle on the
+    rounded operands.  Shapes cover one and several row blocks per strip (64 rows each) and a ragged last one."""
+    B, H, W, C = case
+    rng = np.random.default_rng(zlib_crc(case) + 1)
+    z = dev(r32(rng, B, H, W, C, scale=1.3) + 0.2)
+    w, b = r32(rng, 5, 5, 3, C, scale=0.05), r32(rng, 3, scale=0.1)
+    gm, bt = dev(np.array([1.1], dtype=np.float32)), dev(np.array([-0.15], dtype=np.float32))
+    alpha = 0.3
+    z16 = torch.empty_like(z, dtype=torch.bfloat16)
+    st = ops.instnorm_stats(z, gm, bt, 0, alpha, x16_out=z16)
+    h16 = torch.empty_like(z16)
+    ops.instnorm_apply(z16, st, None, 0, 1, alpha, out16=h16, want_f32=False)
+    pack = ops.conv_pack(dev(w), 3, C, 1)
+    assert ops.convT_s1_tanh_fwd_z16_supported(H, W, 3, C, 1) and not ops.convT_s1_tanh_fwd_z16_supported(H, W + 8, 3, C, 1)
+    y_ref = ops.convT_s1_tanh_fwd(None, pack, dev(b), 3, 1, x16=h16)
+    y = ops.convT_s1_tanh_fwd_z16(z16, st, alpha, pack, dev(b), 3, 1)
+    assert torch.equal(y, y_ref)
+    exp = np.tanh(O.conv2d_transpose(h16.double().cpu().numpy(), _bf16_round(w), b, 1))
+    assert rel(y, exp) < 3e-5
+
+
 def zlib_crc(case):
     import zlib
     return zlib.crc32(repr(case).encode())
