@@ -1,0 +1,6 @@
+set -e
+cd $GRAFT_REPO_ROOT
+for d in 0 1 2 4 3 6; do
+  touch littlegan_amd/csrc/wgrad_at.hip; LG_EXTRA_FLAGS="-DLG_WGAT_DBG=$d" python -m littlegan_amd.csrc.build > /dev/null 2>&1
+  echo "DBG=$d"; timeout -k 10 100 python scripts/bench_layer.py "wgrad 32/64" "wgrad 64/128"
+done
