@@ -120,10 +120,19 @@ __global__ __launch_bounds__(256) void dense_dgrad_kernel(const float* __restric
 
 }  // namespace
 
+extern "C" int lg_dense_fwd_mfma_try(const float* x, const float* w, const float* bias, float* y, int B, int K, int N,
+                                     void* stream);
+extern "C" int lg_dense_wgrad_mfma_try(const float* x, const float* dy, float* dw, float* db, int B, int K, int N, int accumulate,
+                                       void* stream);
+
 extern "C" int lg_dense_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N,
                             void* stream) {
   LG_CHECK_ARG(x && w && y, "lg_dense_fwd: null pointer");
   LG_CHECK_ARG(B > 0 && K > 0 && K <= 1024 && N > 0 && N % 4 == 0, "lg_dense_fwd: bad shape B=%d K=%d N=%d", B, K, N);
+  {
+    const int rc = lg_dense_fwd_mfma_try(x, w, bias, y, B, K, N, stream);  // aligned shapes: fp32 matrix instruction
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+  }
   constexpr int TB = 8;
   dim3 grid(lg_cdiv(N, 1024), lg_cdiv(B, TB));
   hipLaunchKernelGGL(dense_fwd_kernel<TB>, grid, dim3(256), TB * K * sizeof(float), (hipStream_t)stream, x, w, bias, y,
@@ -136,6 +145,10 @@ extern "C" int lg_dense_wgrad(const float* x, const float* dy, float* dw, float*
                               int accumulate, void* stream) {
   LG_CHECK_ARG(x && dy && dw, "lg_dense_wgrad: null pointer");
   LG_CHECK_ARG(B > 0 && K > 0 && N > 0 && N % 4 == 0, "lg_dense_wgrad: bad shape B=%d K=%d N=%d", B, K, N);
+  {
+    const int rc = lg_dense_wgrad_mfma_try(x, dy, dw, db, B, K, N, accumulate, stream);
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+  }
   constexpr int KT = 16;
   const size_t lds = ((size_t)((B * KT + 3) / 4) * 4 + (size_t)(KT + 1) * 64 * 4) * sizeof(float);
   LG_CHECK_ARG(lds <= 160 * 1024, "lg_dense_wgrad: batch %d too large for the LDS staging of x", B);

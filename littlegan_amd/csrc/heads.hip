@@ -193,6 +193,13 @@ __global__ __launch_bounds__(256) void heads_wgrad_kernel(const float* __restric
 
 }  // namespace
 
+extern "C" int lg_heads_fwd_mfma_try(const float* x, const float* wpr, const float* wc, float* part, int B, int K, int c,
+                                     int* nkc_out, void* stream);
+extern "C" int lg_heads_wgrad_mfma_try(const float* x, const float* dz, float* dwpr, float* dbpr, float* dwc, float* dbc, int B,
+                                       int K, int c, int accumulate, void* stream);
+extern "C" int lg_heads_dgrad_mfma_try(const float* dz, const float* wpr, const float* wc, float* dx, int B, int K, int c,
+                                       void* stream);
+
 extern "C" size_t lg_heads_fwd_workspace_bytes(int B, int K, int c) {
   return (size_t)lg_cdiv(K, FKC) * (size_t)B * (size_t)(c + 1) * sizeof(float);
 }
@@ -202,11 +209,15 @@ extern "C" int lg_heads_fwd(const float* x, const float* wpr, const float* bpr, 
   LG_CHECK_ARG(x && wpr && bpr && wc && bc && p && workspace, "lg_heads_fwd: null pointer");
   LG_CHECK_ARG(B > 0 && K > 0 && K % 4 == 0 && c >= 1 && c <= HC_MAX, "lg_heads_fwd: bad shape B=%d K=%d c=%d", B, K, c);
   LG_CHECK_ARG(ws_bytes >= lg_heads_fwd_workspace_bytes(B, K, c), "lg_heads_fwd: workspace too small (%zu bytes)", ws_bytes);
-  const int nkc = lg_cdiv(K, FKC);
+  int nkc = lg_cdiv(K, FKC);
   float* part = (float*)workspace;
-  hipLaunchKernelGGL(heads_fwd_kernel, dim3(nkc, lg_cdiv(B, FS)), dim3(256), 0, (hipStream_t)stream, x, wpr, wc, part,
-                     B, K, c);
-  LG_CHECK_LAUNCH("lg_heads_fwd");
+  const int rc = lg_heads_fwd_mfma_try(x, wpr, wc, part, B, K, c, &nkc, stream);  // aligned shapes: fp32 matrix instruction
+  if (rc != LG_OK && rc != LG_ERR_UNSUPPORTED) return rc;
+  if (rc == LG_ERR_UNSUPPORTED) {
+    hipLaunchKernelGGL(heads_fwd_kernel, dim3(nkc, lg_cdiv(B, FS)), dim3(256), 0, (hipStream_t)stream, x, wpr, wc, part,
+                       B, K, c);
+    LG_CHECK_LAUNCH("lg_heads_fwd");
+  }
   hipLaunchKernelGGL(heads_final_kernel, dim3(lg_cdiv(B * (c + 1), 256)), dim3(256), 0, (hipStream_t)stream, part, bpr,
                      bc, p, B, c, nkc);
   LG_CHECK_LAUNCH("lg_heads_fwd(final)");
@@ -217,6 +228,10 @@ extern "C" int lg_heads_dgrad(const float* dz, const float* wpr, const float* wc
                               void* stream) {
   LG_CHECK_ARG(dz && wpr && wc && dx, "lg_heads_dgrad: null pointer");
   LG_CHECK_ARG(B > 0 && K > 0 && c >= 1 && c <= HC_MAX, "lg_heads_dgrad: bad shape B=%d K=%d c=%d", B, K, c);
+  {
+    const int rc = lg_heads_dgrad_mfma_try(dz, wpr, wc, dx, B, K, c, stream);
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+  }
   dim3 grid(lg_cdiv(K, 256), lg_cdiv(B, DB));
   const size_t lds = (size_t)((256 * (c | 1) + 3) / 4 * 4 + DB * (c + 1)) * sizeof(float);
   hipLaunchKernelGGL(heads_dgrad_kernel, grid, dim3(256), lds, (hipStream_t)stream, dz, wpr, wc, dx, B, K, c);
@@ -228,6 +243,10 @@ extern "C" int lg_heads_wgrad(const float* x, const float* dz, float* dwpr, floa
                               int K, int c, int accumulate, void* stream) {
   LG_CHECK_ARG(x && dz && dwpr && dbpr && dwc && dbc, "lg_heads_wgrad: null pointer");
   LG_CHECK_ARG(B > 0 && K > 0 && K % 4 == 0 && c >= 1 && c <= HC_MAX, "lg_heads_wgrad: bad shape B=%d K=%d c=%d", B, K, c);
+  {
+    const int rc = lg_heads_wgrad_mfma_try(x, dz, dwpr, dbpr, dwc, dbc, B, K, c, accumulate, stream);
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+  }
   hipLaunchKernelGGL(heads_wgrad_kernel, dim3(lg_cdiv(K, WK)), dim3(256), 0, (hipStream_t)stream, x, dz, dwpr, dbpr,
                      dwc, dbc, B, K, c, accumulate);
   LG_CHECK_LAUNCH("lg_heads_wgrad");
