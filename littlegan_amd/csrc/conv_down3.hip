@@ -28,17 +28,26 @@ namespace {
 
 constexpr int TH = 8, TW = 16;                 // output tile (pixels)
 constexpr int HH = 2 * TH + 3;                 // halo rows  (19)
-constexpr int HWH = 18, HWP = 2 * HWH;         // halo pixel row: 18 even + 18 odd column slots (35 used)
-constexpr int NROWS = HH * HWP;                // 684 halo pixels per tile
 constexpr int ROWB = 48;                       // LDS pitch of a halo pixel (32 B of channels + 16 B)
-constexpr int HB = NROWS * ROWB;               // 32832 B per buffer
-constexpr int NPIECE = NROWS * 2;              // 16-B pieces per slice
-constexpr int PPT = (NPIECE + 255) / 256;      // pieces per thread (6)
 constexpr int KC = 16;                         // channels per slice = one MFMA k-step
 constexpr int NTAP = 25;
-constexpr int SRED_OFF = 2 * HB;               // 16 doubles of reduction scratch behind the two buffers
-constexpr int SBIAS_OFF = 2 * HB + 256;        // 128 floats: bias of the block's current column tile
-constexpr int LDS_BYTES = 2 * HB + 256 + 512;
+// Halo image of a tile.  A pixel row is stored de-interleaved: HWH even-column slots, then HWH odd-column slots.
+//   default: one sample, 8 x 16 output pixels -> 35 halo columns, 18 + 18 slots.
+//   PAIR (8 x 8 maps): the tile is TWO samples side by side (columns 0..7 = sample n, 8..15 = sample n + 1), each with its
+//   own 19-column halo: slots 0..9 / 10..19 of both arrays (22 + 22 slots).  HWP = 4 (mod 8) keeps the two tile rows of a
+//   16-lane fragment-read group 8 slots apart, and such a group never mixes the two samples (pix32), so the reads stay
+//   conflict-free whatever the distance between the two halo images.
+template <bool PAIR>
+struct D3L {
+  static constexpr int HWH = PAIR ? 22 : 18, HWP = 2 * HWH;
+  static constexpr int NROWS = HH * HWP;               // halo pixels per tile (684 | 836)
+  static constexpr int HB = NROWS * ROWB;              // bytes per buffer (32832 | 40128)
+  static constexpr int NPIECE = NROWS * 2;             // 16-B pieces per slice
+  static constexpr int PPT = (NPIECE + 255) / 256;     // pieces per thread (6 | 7)
+  static constexpr int SRED_OFF = 2 * HB;              // 32 doubles of reduction scratch behind the two buffers
+  static constexpr int SBIAS_OFF = 2 * HB + 256;       // 128 floats: bias of the block's current column tile
+  static constexpr int LDS_BYTES = 2 * HB + 256 + 512;
+};
 #ifndef LG_D3_DBG
 #define LG_D3_DBG 0   // compile-time ablation bits (timing only, results wrong): 1 no MFMA, 2 no fragment loads, 4 no halo staging, 8 no epilogue
 #endif
@@ -64,13 +73,16 @@ __device__ __forceinline__ int pix32(int r) {  // MFMA row -> tile pixel inside 
   return odd * 16 + rank * 4 + lo;
 }
 
+template <bool PAIR>
 constexpr int toff_bytes(int t) {  // tap t = ky*5+kx: LDS byte offset of its source pixel relative to the lane's base
-  return ((t / 5) * HWP + ((t % 5) >> 1) + ((t % 5) & 1) * HWH) * ROWB;
+  return ((t / 5) * D3L<PAIR>::HWP + ((t % 5) >> 1) + ((t % 5) & 1) * D3L<PAIR>::HWH) * ROWB;
 }
 
-template <bool STATS, bool FUSE = false>
+template <bool STATS, bool FUSE = false, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   static_assert(!(STATS && FUSE), "forward moments and backward sums are never needed together");
+  using L = D3L<PAIR>;
+  constexpr int HWH = L::HWH, HWP = L::HWP, HB = L::HB, NPIECE = L::NPIECE, PPT = L::PPT, SRED_OFF = L::SRED_OFF, SBIAS_OFF = L::SBIAS_OFF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* sred = reinterpret_cast<double*>(smem + SRED_OFF);
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -89,9 +101,14 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
     pl[u] = -1; pyx[u] = 0;
     if (q < NPIECE) {
       const int row = q >> 1, hy = row / HWP, hxp = row - hy * HWP;
-      const int hx = hxp < HWH ? 2 * hxp : 2 * (hxp - HWH) + 1;
       pl[u] = row * ROWB + (q & 1) * 16;
-      pyx[u] = hx < 2 * TW + 3 ? (hy << 8) | hx : (0x7fff << 8);  // the 36th slot of a row is padding: never valid
+      if constexpr (PAIR) {  // slot j of an array: sample j / 10, halo column 2 (j % 10) (+1 in the odd array); 20, 21 = padding
+        const int odd = hxp >= HWH, j = hxp - odd * HWH, sm = j / 10, hx = 2 * (j - sm * 10) + odd;
+        pyx[u] = (j < 20 && hx < 2 * 8 + 3) ? (hy << 8) | (sm << 7) | hx : (0x7fff << 8);
+      } else {
+        const int hx = hxp < HWH ? 2 * hxp : 2 * (hxp - HWH) + 1;
+        pyx[u] = hx < 2 * TW + 3 ? (hy << 8) | hx : (0x7fff << 8);  // the 36th slot of a row is padding: never valid
+      }
     }
   }
   const int half8 = (tid & 1) * 8;  // channel offset of this thread's pieces inside the slice (256 is even: same for all)
@@ -101,7 +118,8 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = i * 32 + pix32(r);
-    abase[i] = (2 * (m >> 4) * HWP + (m & 15)) * ROWB + h * 16;
+    const int col = m & 15;
+    abase[i] = (2 * (m >> 4) * HWP + (PAIR ? col + 2 * (col >> 3) : col)) * ROWB + h * 16;  // PAIR: sample 1 starts at slot 10
   }
 
   struct Item { int n, y0, x0, tn; };
@@ -110,6 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
     Item it;
     it.tn = item % p.ntn;
     const int tm = item / p.ntn;
+    if constexpr (PAIR) { it.n = 2 * tm; it.y0 = 0; it.x0 = 0; return it; }
     it.n = tm / p.tpi;
     const int tt = tm - it.n * p.tpi;
     it.y0 = (tt / p.tpi_x) * TH; it.x0 = (tt % p.tpi_x) * TW;
@@ -120,9 +139,10 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
     for (int u = 0; u < PPT; ++u) {
       v[u] = u32x4{0u, 0u, 0u, 0u};
       if (pl[u] >= 0) {
-        const int sy = 2 * it.y0 - 1 + (pyx[u] >> 8), sx = 2 * it.x0 - 1 + (pyx[u] & 255);
+        const int sy = 2 * it.y0 - 1 + (pyx[u] >> 8), sx = 2 * it.x0 - 1 + (pyx[u] & (PAIR ? 127 : 255));
+        const int sn = it.n + (PAIR ? (pyx[u] >> 7) & 1 : 0);
         if ((unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
-          v[u] = *reinterpret_cast<const u32x4*>(p.src + ((long long)(it.n * p.Hs + sy) * p.Ws + sx) * p.Cs + c0 + half8);
+          v[u] = *reinterpret_cast<const u32x4*>(p.src + ((long long)(sn * p.Hs + sy) * p.Ws + sx) * p.Cs + c0 + half8);
       }
     }
   };
@@ -202,13 +222,13 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
     // MFMAs of tap t issue, then the ring slot they freed is refilled RING taps ahead.
     bf16x8 a[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes(0));
+    for (int i = 0; i < 4; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes<PAIR>(0));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) {
       if (t + 1 < NTAP) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[(t + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes(t + 1 < NTAP ? t + 1 : 0));
+        for (int i = 0; i < 4; ++i) a[(t + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes<PAIR>(t + 1 < NTAP ? t + 1 : 0));
       }
       __builtin_amdgcn_sched_barrier(0);
       const int slot = (t + OFF) % RING;
@@ -261,10 +281,26 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
         }
       }
       if constexpr (STATS) {
-        const double w1 = lg_wave_sum_d((double)s1v[0] + (double)s1v[1]), w2 = lg_wave_sum_d((double)s2v[0] + (double)s2v[1]);
-        if (lane == 0) { sred[(k & 1) * 8 + wid] = w1; sred[(k & 1) * 8 + 4 + wid] = w2; }
+        const double l1 = (double)s1v[0] + (double)s1v[1], l2 = (double)s2v[0] + (double)s2v[1];
+        if constexpr (PAIR) {  // a lane's 128 values all belong to ONE sample (its tile column never changes): masked sums
+          const bool sb = (pix32(r) & 8) != 0;
+          const double a1 = lg_wave_sum_d(sb ? 0.0 : l1), a2 = lg_wave_sum_d(sb ? 0.0 : l2);
+          const double b1 = lg_wave_sum_d(sb ? l1 : 0.0), b2 = lg_wave_sum_d(sb ? l2 : 0.0);
+          if (lane == 0) {
+            double* q = sred + (k & 1) * 16;
+            q[wid] = a1; q[4 + wid] = a2; q[8 + wid] = b1; q[12 + wid] = b2;
+          }
+        } else {
+          const double w1 = lg_wave_sum_d(l1), w2 = lg_wave_sum_d(l2);
+          if (lane == 0) { sred[(k & 1) * 16 + wid] = w1; sred[(k & 1) * 16 + 4 + wid] = w2; }
+        }
       }
+      // element offset of tile pixel `row` (= 16 y + column) in the output / in z.  PAIR: columns 8..15 are sample n + 1
       const long long obase = ((long long)(cur.n * p.Hm + cur.y0) * p.Wm + cur.x0) * p.N + cur.tn * 128;
+      auto pix_off = [&](int row) -> long long {
+        if constexpr (PAIR) return obase + (long long)(((row >> 3) & 1) * 64 + (row >> 4) * 8 + (row & 7)) * p.N;
+        else return obase + ((long long)(row >> 4) * p.Wm + (row & 15)) * p.N;
+      };
       // FUSE: the z pieces of the row sweep are requested now — the accumulators are dead (staged), the loads land behind
       // the barrier instead of in front of every use
       u32x4 zq[FUSE ? 8 : 1];
@@ -273,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
 #pragma unroll
         for (int q8 = 0; q8 < 8; ++q8) {
           const int piece = tid + q8 * 256, row = piece >> 4, j = piece & 15;
-          zq[q8] = *reinterpret_cast<const u32x4*>(p.nf.z + obase + ((long long)(row >> 4) * p.Wm + (row & 15)) * p.N + j * 8);
+          zq[q8] = *reinterpret_cast<const u32x4*>(p.nf.z + pix_off(row) + j * 8);
         }
       }
       __syncthreads();  // tile complete in LDS (and the wave sums)
@@ -283,35 +319,56 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
       for (int q8 = 0; q8 < 8; ++q8) {
         const int piece = tid + q8 * 256, row = piece >> 4, j = piece & 15;
         const u32x4 v = *reinterpret_cast<const u32x4*>(C + row * 256 + ((j ^ (row & 15)) << 4));
-        const long long goff = obase + ((long long)(row >> 4) * p.Wm + (row & 15)) * p.N + j * 8;
+        const long long goff = pix_off(row) + j * 8;
         *reinterpret_cast<u32x4*>(p.out + goff) = v;
         if constexpr (FUSE) {
-          const float* sp = p.nf.stats + (long long)cur.n * 8;
+          // PAIR: the tile column of a thread's pieces is fixed ((tid >> 4) & 15): waves 0, 1 sweep sample n, waves 2, 3 n + 1
+          const float* sp = p.nf.stats + (long long)(cur.n + (PAIR ? wid >> 1 : 0)) * 8;
           lg_nf_accum(v, zq[q8], sp[0], sp[4], sp[2], sp[3], p.nf.alpha, nf1, nf2);
         }
       }
       if constexpr (FUSE) {
         const double w1 = lg_wave_sum_d((double)nf1), w2 = lg_wave_sum_d((double)nf2);
-        if (lane == 0) { sred[(k & 1) * 8 + wid] = w1; sred[(k & 1) * 8 + 4 + wid] = w2; }
+        if (lane == 0) { sred[(k & 1) * 16 + wid] = w1; sred[(k & 1) * 16 + 4 + wid] = w2; }
       }
       if constexpr (STATS) {
         if (tid == 0) {
-          constexpr double cnt = 128.0 * 128.0;
-          const double* q = sred + (k & 1) * 8;
-          const double S1 = (q[0] + q[1]) + (q[2] + q[3]), S2 = (q[4] + q[5]) + (q[6] + q[7]);
-          const double md = S1 / cnt;
-          const int tin = (cur.y0 / TH) * p.tpi_x + cur.x0 / TW;
-          double* o = p.spart + ((long long)cur.n * p.nparts + tin * p.ntn + cur.tn) * 3;
-          o[0] = cnt; o[1] = (double)shift + md; o[2] = S2 - cnt * md * md;
+          const double* q = sred + (k & 1) * 16;
+          if constexpr (PAIR) {
+            constexpr double cnt = 64.0 * 128.0;
+#pragma unroll
+            for (int sm = 0; sm < 2; ++sm) {
+              const double S1 = (q[8 * sm] + q[8 * sm + 1]) + (q[8 * sm + 2] + q[8 * sm + 3]);
+              const double S2 = (q[8 * sm + 4] + q[8 * sm + 5]) + (q[8 * sm + 6] + q[8 * sm + 7]);
+              const double md = S1 / cnt;
+              double* o = p.spart + ((long long)(cur.n + sm) * p.nparts + cur.tn) * 3;
+              o[0] = cnt; o[1] = (double)shift + md; o[2] = S2 - cnt * md * md;
+            }
+          } else {
+            constexpr double cnt = 128.0 * 128.0;
+            const double S1 = (q[0] + q[1]) + (q[2] + q[3]), S2 = (q[4] + q[5]) + (q[6] + q[7]);
+            const double md = S1 / cnt;
+            const int tin = (cur.y0 / TH) * p.tpi_x + cur.x0 / TW;
+            double* o = p.spart + ((long long)cur.n * p.nparts + tin * p.ntn + cur.tn) * 3;
+            o[0] = cnt; o[1] = (double)shift + md; o[2] = S2 - cnt * md * md;
+          }
         }
       }
       __syncthreads();  // C fully read before the buffer is staged again (sred alternates between two sets of slots)
       if constexpr (FUSE) {
         if (tid == 0) {
-          const double* q = sred + (k & 1) * 8;
-          const int tin = (cur.y0 / TH) * p.tpi_x + cur.x0 / TW;
-          double* o = p.nf.part + ((long long)cur.n * p.nparts + tin * p.ntn + cur.tn) * 2;
-          o[0] = (q[0] + q[1]) + (q[2] + q[3]); o[1] = (q[4] + q[5]) + (q[6] + q[7]);
+          const double* q = sred + (k & 1) * 16;
+          if constexpr (PAIR) {
+#pragma unroll
+            for (int sm = 0; sm < 2; ++sm) {
+              double* o = p.nf.part + ((long long)(cur.n + sm) * p.nparts + cur.tn) * 2;
+              o[0] = q[2 * sm] + q[2 * sm + 1]; o[1] = q[4 + 2 * sm] + q[4 + 2 * sm + 1];
+            }
+          } else {
+            const int tin = (cur.y0 / TH) * p.tpi_x + cur.x0 / TW;
+            double* o = p.nf.part + ((long long)cur.n * p.nparts + tin * p.ntn + cur.tn) * 2;
+            o[0] = (q[0] + q[1]) + (q[2] + q[3]); o[1] = (q[4] + q[5]) + (q[6] + q[7]);
+          }
         }
       }
 #pragma unroll
@@ -349,12 +406,13 @@ extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const 
   static int off = -1;
   if (off < 0) off = getenv("LG_NO_DOWN3") ? 1 : 0;  // A/B switch
   if (off || !src16 || !wpack || !out16) return LG_ERR_UNSUPPORTED;
-  if (Hm % TH || Wm % TW || Cs % KC || N % 128 || B <= 0) return LG_ERR_UNSUPPORTED;
+  const bool pair = Hm == 8 && Wm == 8 && B % 2 == 0;  // 8 x 8 maps: a tile = two samples side by side
+  if (((Hm % TH || Wm % TW) && !pair) || Cs % KC || N % 128 || B <= 0) return LG_ERR_UNSUPPORTED;
   D3Params p{};
   p.src = (const __bf16*)src16; p.wp = (const char*)wpack; p.bias = bias; p.out = (__bf16*)out16;
   p.B = B; p.Hm = Hm; p.Wm = Wm; p.Hs = 2 * Hm; p.Ws = 2 * Wm; p.Cs = Cs; p.N = N; p.N32 = N / 32; p.KB = Cs / 16;
-  p.tpi_x = Wm / TW; p.tpi = p.tpi_x * (Hm / TH); p.ntn = N / 128;
-  const long long nitems = (long long)B * p.tpi * p.ntn;
+  p.tpi_x = pair ? 1 : Wm / TW; p.tpi = pair ? 1 : p.tpi_x * (Hm / TH); p.ntn = N / 128;
+  const long long nitems = (long long)(pair ? B / 2 : B) * p.tpi * p.ntn;
   if (nitems <= 0 || nitems >= (1ll << 30)) return LG_ERR_UNSUPPORTED;
   p.nitems = (int)nitems; p.nparts = p.tpi * p.ntn;
   { static int stg = -1; if (stg < 0) { const char* e = getenv("LG_D3_STAGGER"); stg = e ? atoi(e) : 6; } p.stagger = stg; }
@@ -373,20 +431,29 @@ extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const 
       if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
     }
     nblk = 2 * cus;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_down3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_down3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_down3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_down3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<true, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<true>::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<true>::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<true>::LDS_BYTES);
   }
   const int grid = p.nitems < nblk ? p.nitems : nblk;
   hipStream_t st = (hipStream_t)stream;
-  if (fuse) hipLaunchKernelGGL((conv_down3_kernel<false, true>), dim3(grid), dim3(256), LDS_BYTES, st, p);
-  else if (stats) hipLaunchKernelGGL(conv_down3_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, st, p);
-  else hipLaunchKernelGGL(conv_down3_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, st, p);
+  constexpr int LDS0 = D3L<false>::LDS_BYTES, LDS1 = D3L<true>::LDS_BYTES;
+  if (pair) {
+    if (fuse) hipLaunchKernelGGL((conv_down3_kernel<false, true, true>), dim3(grid), dim3(256), LDS1, st, p);
+    else if (stats) hipLaunchKernelGGL((conv_down3_kernel<true, false, true>), dim3(grid), dim3(256), LDS1, st, p);
+    else hipLaunchKernelGGL((conv_down3_kernel<false, false, true>), dim3(grid), dim3(256), LDS1, st, p);
+  } else if (fuse) hipLaunchKernelGGL((conv_down3_kernel<false, true>), dim3(grid), dim3(256), LDS0, st, p);
+  else if (stats) hipLaunchKernelGGL(conv_down3_kernel<true>, dim3(grid), dim3(256), LDS0, st, p);
+  else hipLaunchKernelGGL(conv_down3_kernel<false>, dim3(grid), dim3(256), LDS0, st, p);
   LG_CHECK_LAUNCH("lg_conv_down3");
   if (stats || fuse) *nparts_out = p.nparts;
   return LG_OK;
 }
 
 extern "C" int lg_conv_down3_supported(int B, int Hm, int Wm, int Cs, int N) {
-  return (!getenv("LG_NO_DOWN3") && B > 0 && Hm % TH == 0 && Wm % TW == 0 && Cs % KC == 0 && N % 128 == 0) ? 1 : 0;
+  const bool pair = Hm == 8 && Wm == 8 && B % 2 == 0;
+  return (!getenv("LG_NO_DOWN3") && B > 0 && ((Hm % TH == 0 && Wm % TW == 0) || pair) && Cs % KC == 0 && N % 128 == 0) ? 1 : 0;
 }
