@@ -78,15 +78,21 @@ constexpr int toff_bytes(int t) {  // tap t = ky*5+kx: LDS byte offset of its so
   return ((t / 5) * D3L<PAIR>::HWP + ((t % 5) >> 1) + ((t % 5) & 1) * D3L<PAIR>::HWH) * ROWB;
 }
 
-template <bool STATS, bool FUSE = false, bool PAIR = false>
+// NW = output channels per tile: 128 (each of the 4 waves owns 32 channels x all 128 pixels) or 64 (2 x 2 waves: 32 channels
+// x 64 pixels each — half the MFMAs per weight fragment, for the layers whose N is only a multiple of 64)
+template <bool STATS, bool FUSE = false, bool PAIR = false, int NW = 128>
 __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   static_assert(!(STATS && FUSE), "forward moments and backward sums are never needed together");
+  static_assert(NW == 128 || (NW == 64 && !PAIR), "tile widths");
+  constexpr int NWV = NW / 32, NI = NW / 32;          // waves along the channels; 32-pixel groups per wave (4 | 2)
+  constexpr int PPR = NW / 8, NQ = 128 * PPR / 256;   // 16-B pieces per output pixel row; pieces per thread in the row sweep
   using L = D3L<PAIR>;
   constexpr int HWH = L::HWH, HWP = L::HWP, HB = L::HB, NPIECE = L::NPIECE, PPT = L::PPT, SRED_OFF = L::SRED_OFF, SBIAS_OFF = L::SBIAS_OFF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* sred = reinterpret_cast<double*>(smem + SRED_OFF);
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: the weight addresses stay in SGPRs
+  const int wn = wid % NWV, wm = wid / NWV;                  // this wave: channels 32 wn .., pixel groups wm * NI ..
   const int G = gridDim.x;
   const int lb = lg_xcd_remap(blockIdx.x, G);
   const int nmine = (p.nitems - lb + G - 1) / G;  // items lb, lb + G, ...   (grid <= nitems)
@@ -114,10 +120,10 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   const int half8 = (tid & 1) * 8;  // channel offset of this thread's pieces inside the slice (256 is even: same for all)
 
   // ---- per-lane A bases: pixel m = i*32 + pix32(r) of the 8 x 16 tile -> halo pixel (2 ly, lx) of the even columns ----
-  int abase[4];
+  int abase[NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = i * 32 + pix32(r);
+  for (int i = 0; i < NI; ++i) {
+    const int m = (wm * NI + i) * 32 + pix32(r);
     const int col = m & 15;
     abase[i] = (2 * (m >> 4) * HWP + (PAIR ? col + 2 * (col >> 3) : col)) * ROWB + h * 16;  // PAIR: sample 1 starts at slot 10
   }
@@ -155,15 +161,15 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   const unsigned lane16 = lane * 16;
   const unsigned wstride = (unsigned)p.N32 * (unsigned)p.KB * 1024u;  // bytes from one tap's fragments to the next tap's
   auto wbase = [&](int tn, int kb) {  // uniform 64-bit base (SGPRs) of (column tile, k-step); taps are wstride apart
-    return p.wp + ((long long)(tn * 4 + wid) * p.KB + kb) * 1024;
+    return p.wp + ((long long)(tn * NWV + wn) * p.KB + kb) * 1024;
   };
   auto wfrag = [&](const char* base, int t) {  // SGPR base + 32-bit lane offset: no 64-bit arithmetic in the tap loop
     return *reinterpret_cast<const u32x4*>((base + (unsigned long long)t * wstride) + lane16);  // scalar add, lane offset
   };
 
-  f32x16 acc[4];
+  f32x16 acc[NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
   // Weight-fragment ring: RING fragments (= taps) ahead of the MFMAs.  25 taps per slice and RING = 10 -> the ring
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   // the one-pass moments
   float* sbias = reinterpret_cast<float*>(smem + SBIAS_OFF);
   auto load_bias = [&](int tn) {  // (a barrier lies between this and the next epilogue that reads it)
-    if (tid < 128) sbias[tid] = p.bias ? p.bias[tn * 128 + tid] : 0.f;
+    if (tid < NW) sbias[tid] = p.bias ? p.bias[tn * NW + tid] : 0.f;
   };
   load_bias(cur.tn);
   {  // Two blocks share a CU (one wave of each per SIMD) and run the same periodic program: started together they stay
@@ -220,20 +226,20 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
     // serialises each MFMA behind its own LDS read (measured in the .s: "ds_read; s_waitcnt lgkmcnt(0); v_mfma" per
     // MFMA, "global_load; s_waitcnt vmcnt(0)" per tap).  Per tap: the A fragments of tap t+1 are requested, then the 4
     // MFMAs of tap t issue, then the ring slot they freed is refilled RING taps ahead.
-    bf16x8 a[2][4];
+    bf16x8 a[2][NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes<PAIR>(0));
+    for (int i = 0; i < NI; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes<PAIR>(0));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) {
       if (t + 1 < NTAP) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[(t + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes<PAIR>(t + 1 < NTAP ? t + 1 : 0));
+        for (int i = 0; i < NI; ++i) a[(t + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes<PAIR>(t + 1 < NTAP ? t + 1 : 0));
       }
       __builtin_amdgcn_sched_barrier(0);
       const int slot = (t + OFF) % RING;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)  // transposed product: rows = this wave's 32 output channels, columns = 32 pixels
+      for (int i = 0; i < NI; ++i)  // transposed product: rows = this wave's 32 output channels, columns = 32 pixels
         if constexpr (!(DBG & 1)) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[slot]), a[t & 1][i], acc[i], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       // the slot is free: request the fragment RING taps ahead (this slice, or the next one)
@@ -258,10 +264,10 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
       f32x2 s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
       f32x4 bq[4];  // bias of channels 8g + 4h + {0..3} of this wave's 32
 #pragma unroll
-      for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(sbias + wid * 32 + 8 * g + 4 * h);
+      for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(sbias + wn * 32 + 8 * g + 4 * h);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = i * 32 + pix32(r);
+      for (int i = 0; i < NI; ++i) {
+        const int row = (wm * NI + i) * 32 + pix32(r);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           bf16x4 w;
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
           }
           // 16-B piece (wid*4 + g) of the 256-B row, XOR-swizzled by the row so that both the 8-B writes of a lane group
           // (16 rows, same piece) and the 16-B row reads (same row, 16 pieces) are conflict-free
-          *reinterpret_cast<bf16x4*>(C + row * 256 + (((wid * 4 + g) ^ (row & 15)) << 4) + 8 * h) = w;
+          *reinterpret_cast<bf16x4*>(C + row * (NW * 2) + (((wn * 4 + g) ^ (row & (PPR - 1))) << 4) + 8 * h) = w;
         }
       }
       if constexpr (STATS) {
@@ -296,19 +302,19 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
         }
       }
       // element offset of tile pixel `row` (= 16 y + column) in the output / in z.  PAIR: columns 8..15 are sample n + 1
-      const long long obase = ((long long)(cur.n * p.Hm + cur.y0) * p.Wm + cur.x0) * p.N + cur.tn * 128;
+      const long long obase = ((long long)(cur.n * p.Hm + cur.y0) * p.Wm + cur.x0) * p.N + cur.tn * NW;
       auto pix_off = [&](int row) -> long long {
         if constexpr (PAIR) return obase + (long long)(((row >> 3) & 1) * 64 + (row >> 4) * 8 + (row & 7)) * p.N;
         else return obase + ((long long)(row >> 4) * p.Wm + (row & 15)) * p.N;
       };
       // FUSE: the z pieces of the row sweep are requested now — the accumulators are dead (staged), the loads land behind
       // the barrier instead of in front of every use
-      u32x4 zq[FUSE ? 8 : 1];
+      u32x4 zq[FUSE ? NQ : 1];
       (void)zq;
       if constexpr (FUSE) {
 #pragma unroll
-        for (int q8 = 0; q8 < 8; ++q8) {
-          const int piece = tid + q8 * 256, row = piece >> 4, j = piece & 15;
+        for (int q8 = 0; q8 < NQ; ++q8) {
+          const int piece = tid + q8 * 256, row = piece / PPR, j = piece % PPR;
           zq[q8] = *reinterpret_cast<const u32x4*>(p.nf.z + pix_off(row) + j * 8);
         }
       }
@@ -316,9 +322,9 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
       float nf1 = 0.f, nf2 = 0.f;
       (void)nf1; (void)nf2;
 #pragma unroll
-      for (int q8 = 0; q8 < 8; ++q8) {
-        const int piece = tid + q8 * 256, row = piece >> 4, j = piece & 15;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(C + row * 256 + ((j ^ (row & 15)) << 4));
+      for (int q8 = 0; q8 < NQ; ++q8) {
+        const int piece = tid + q8 * 256, row = piece / PPR, j = piece % PPR;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(C + row * (NW * 2) + ((j ^ (row & (PPR - 1))) << 4));
         const long long goff = pix_off(row) + j * 8;
         *reinterpret_cast<u32x4*>(p.out + goff) = v;
         if constexpr (FUSE) {
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
               o[0] = cnt; o[1] = (double)shift + md; o[2] = S2 - cnt * md * md;
             }
           } else {
-            constexpr double cnt = 128.0 * 128.0;
+            constexpr double cnt = 128.0 * NW;
             const double S1 = (q[0] + q[1]) + (q[2] + q[3]), S2 = (q[4] + q[5]) + (q[6] + q[7]);
             const double md = S1 / cnt;
             const int tin = (cur.y0 / TH) * p.tpi_x + cur.x0 / TW;
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
       if (more && nxt.tn != cur.tn) load_bias(nxt.tn);
@@ -407,11 +413,14 @@ extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const 
   if (off < 0) off = getenv("LG_NO_DOWN3") ? 1 : 0;  // A/B switch
   if (off || !src16 || !wpack || !out16) return LG_ERR_UNSUPPORTED;
   const bool pair = Hm == 8 && Wm == 8 && B % 2 == 0;  // 8 x 8 maps: a tile = two samples side by side
-  if (((Hm % TH || Wm % TW) && !pair) || Cs % KC || N % 128 || B <= 0) return LG_ERR_UNSUPPORTED;
+  static int no64 = -1;
+  if (no64 < 0) no64 = getenv("LG_NO_DOWN3_N64") ? 1 : 0;
+  const bool n64 = N % 128 != 0 && N % 64 == 0 && !pair && !no64;  // 64-column tiles (2 x 2 waves)
+  if (((Hm % TH || Wm % TW) && !pair) || Cs % KC || (N % 128 && !n64) || B <= 0) return LG_ERR_UNSUPPORTED;
   D3Params p{};
   p.src = (const __bf16*)src16; p.wp = (const char*)wpack; p.bias = bias; p.out = (__bf16*)out16;
   p.B = B; p.Hm = Hm; p.Wm = Wm; p.Hs = 2 * Hm; p.Ws = 2 * Wm; p.Cs = Cs; p.N = N; p.N32 = N / 32; p.KB = Cs / 16;
-  p.tpi_x = pair ? 1 : Wm / TW; p.tpi = pair ? 1 : p.tpi_x * (Hm / TH); p.ntn = N / 128;
+  p.tpi_x = pair ? 1 : Wm / TW; p.tpi = pair ? 1 : p.tpi_x * (Hm / TH); p.ntn = n64 ? N / 64 : N / 128;
   const long long nitems = (long long)(pair ? B / 2 : B) * p.tpi * p.ntn;
   if (nitems <= 0 || nitems >= (1ll << 30)) return LG_ERR_UNSUPPORTED;
   p.nitems = (int)nitems; p.nparts = p.tpi * p.ntn;
@@ -437,6 +446,9 @@ extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<true, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<true>::LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<true>::LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<true>::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<true, false, false, 64>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, false, false, 64>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, true, false, 64>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
   }
   const int grid = p.nitems < nblk ? p.nitems : nblk;
   hipStream_t st = (hipStream_t)stream;
@@ -445,6 +457,10 @@ extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const 
     if (fuse) hipLaunchKernelGGL((conv_down3_kernel<false, true, true>), dim3(grid), dim3(256), LDS1, st, p);
     else if (stats) hipLaunchKernelGGL((conv_down3_kernel<true, false, true>), dim3(grid), dim3(256), LDS1, st, p);
     else hipLaunchKernelGGL((conv_down3_kernel<false, false, true>), dim3(grid), dim3(256), LDS1, st, p);
+  } else if (n64) {
+    if (fuse) hipLaunchKernelGGL((conv_down3_kernel<false, true, false, 64>), dim3(grid), dim3(256), LDS0, st, p);
+    else if (stats) hipLaunchKernelGGL((conv_down3_kernel<true, false, false, 64>), dim3(grid), dim3(256), LDS0, st, p);
+    else hipLaunchKernelGGL((conv_down3_kernel<false, false, false, 64>), dim3(grid), dim3(256), LDS0, st, p);
   } else if (fuse) hipLaunchKernelGGL((conv_down3_kernel<false, true>), dim3(grid), dim3(256), LDS0, st, p);
   else if (stats) hipLaunchKernelGGL(conv_down3_kernel<true>, dim3(grid), dim3(256), LDS0, st, p);
   else hipLaunchKernelGGL(conv_down3_kernel<false>, dim3(grid), dim3(256), LDS0, st, p);
@@ -455,5 +471,6 @@ extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const 
 
 extern "C" int lg_conv_down3_supported(int B, int Hm, int Wm, int Cs, int N) {
   const bool pair = Hm == 8 && Wm == 8 && B % 2 == 0;
-  return (!getenv("LG_NO_DOWN3") && B > 0 && ((Hm % TH == 0 && Wm % TW == 0) || pair) && Cs % KC == 0 && N % 128 == 0) ? 1 : 0;
+  const bool n64 = N % 128 != 0 && N % 64 == 0 && !pair && !getenv("LG_NO_DOWN3_N64");
+  return (!getenv("LG_NO_DOWN3") && B > 0 && ((Hm % TH == 0 && Wm % TW == 0) || pair) && Cs % KC == 0 && (N % 128 == 0 || n64)) ? 1 : 0;
 }
