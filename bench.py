@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="time the C2 CPU shape at its full batch 64 (minutes)")
+    ap.add_argument("--no-graph-leg", action="store_true", help="skip the extra hipGraph-replay timing (profilers that collect counters cannot follow a graph capture)")
     ap.add_argument("--graph", action="store_true", help="time EagerTrainer.graph_step (captured HIP graphs) instead of eager launches")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo: rehearsal of the N>1 path")
     ap.add_argument("--share-gpu", action="store_true",
@@ -189,6 +190,20 @@ def main():
             tr.train_step_from_inputs(b0 + a.warmup + a.steps + i, inp)
         torch.cuda.synchronize()
     prof = ops.Profile.stop()
+    graph_ms = None
+    profiled = any("rocprof" in (os.environ.get(k) or "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+    if world == 1 and not a.graph and a.workload == "c3" and not a.no_graph_leg and not profiled:
+        # the same steps replayed from captured HIP graphs (EagerTrainer.graph_step, bit-identical results): reported beside
+        # the headline number, which stays the eager one (per-launch HIP events cannot sit inside a replayed graph)
+        bg = b0 + a.warmup + a.steps
+        for i in range(30):  # every step kind at least twice: first eager, then captured
+            tr.graph_step(bg + i, inp)
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        for i in range(30):
+            tr.graph_step(bg + 30 + i, inp)
+        torch.cuda.synchronize()
+        graph_ms = (time.perf_counter() - tg) / 30 * 1e3
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -235,6 +250,8 @@ def main():
                          "conv_share_of_step": round(conv_sec / dt, 3),
                          "conv_tflops_overall": round(conv_fl / conv_sec / 1e12, 2),
                          "step_algorithmic_tflops": round(GFLOP_PER_IMAGE[a.workload] * args.batch_size / ms, 2)},
+            "graph_replay": None if graph_ms is None else {"ms_per_step": round(graph_ms, 3), "value": round(args.batch_size / graph_ms * 1e3, 2),
+                                                               "note": "same steps, one captured hipGraph per step kind, 30 timed steps after the headline region"},
             "losses_last_step": losses,
             "parity": "checked against the in-repo fp64 restatement (tests/); parity to TensorFlow 1.15 is UNPINNED",
         }
