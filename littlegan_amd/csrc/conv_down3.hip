@@ -34,12 +34,14 @@ constexpr int NTAP = 25;
 // Halo image of a tile.  A pixel row is stored de-interleaved: HWH even-column slots, then HWH odd-column slots.
 //   default: one sample, 8 x 16 output pixels -> 35 halo columns, 18 + 18 slots.
 //   PAIR (8 x 8 maps): the tile is TWO samples side by side (columns 0..7 = sample n, 8..15 = sample n + 1), each with its
-//   own 19-column halo: slots 0..9 / 10..19 of both arrays (22 + 22 slots).  HWP = 4 (mod 8) keeps the two tile rows of a
-//   16-lane fragment-read group 8 slots apart, and such a group never mixes the two samples (pix32), so the reads stay
-//   conflict-free whatever the distance between the two halo images.
+//   own 19-column halo.  A ds_read_b128 is served in four 16-lane groups and pix32 makes such a group one tile row = 8
+//   pixels of each sample, 48 B apart: conflict-free only if sample 1's image starts 128 B (mod 256) behind sample 0's.
+//   Slots of a halo row (48 B each): sample 0 even 0..9, odd 10..18, (19..23 unused), sample 1 even 24..33, odd 34..42:
+//   24 slots = 1152 B = 128 (mod 256), the odd arrays sit HWH = 10 slots behind the even ones in both samples, 43 per row.
+//   (Measured with the two images 10 slots apart: SQ_LDS_BANK_CONFLICT = 49 % of the LDS cycles, LDS-active time doubled.)
 template <bool PAIR>
 struct D3L {
-  static constexpr int HWH = PAIR ? 22 : 18, HWP = 2 * HWH;
+  static constexpr int HWH = PAIR ? 10 : 18, HWP = PAIR ? 43 : 2 * HWH;
   static constexpr int NROWS = HH * HWP;               // halo pixels per tile (684 | 836)
   static constexpr int HB = NROWS * ROWB;              // bytes per buffer (32832 | 40128)
   static constexpr int NPIECE = NROWS * 2;             // 16-B pieces per slice
@@ -108,9 +110,9 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
     if (q < NPIECE) {
       const int row = q >> 1, hy = row / HWP, hxp = row - hy * HWP;
       pl[u] = row * ROWB + (q & 1) * 16;
-      if constexpr (PAIR) {  // slot j of an array: sample j / 10, halo column 2 (j % 10) (+1 in the odd array); 20, 21 = padding
-        const int odd = hxp >= HWH, j = hxp - odd * HWH, sm = j / 10, hx = 2 * (j - sm * 10) + odd;
-        pyx[u] = (j < 20 && hx < 2 * 8 + 3) ? (hy << 8) | (sm << 7) | hx : (0x7fff << 8);
+      if constexpr (PAIR) {  // slots 0..19: sample 0 (even 0..9, odd 10..19), 20..23 unused, 24..42: sample 1 (even, odd)
+        const int sm = hxp >= 24, j2 = hxp - 24 * sm, odd = j2 >= HWH, hx = 2 * (j2 - odd * HWH) + odd;
+        pyx[u] = (hxp < 20 || hxp >= 24) && hx < 2 * 8 + 3 ? (hy << 8) | (sm << 7) | hx : (0x7fff << 8);
       } else {
         const int hx = hxp < HWH ? 2 * hxp : 2 * (hxp - HWH) + 1;
         pyx[u] = hx < 2 * TW + 3 ? (hy << 8) | hx : (0x7fff << 8);  // the 36th slot of a row is padding: never valid
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   for (int i = 0; i < NI; ++i) {
     const int m = (wm * NI + i) * 32 + pix32(r);
     const int col = m & 15;
-    abase[i] = (2 * (m >> 4) * HWP + (PAIR ? col + 2 * (col >> 3) : col)) * ROWB + h * 16;  // PAIR: sample 1 starts at slot 10
+    abase[i] = (2 * (m >> 4) * HWP + (PAIR ? col + 16 * (col >> 3) : col)) * ROWB + h * 16;  // PAIR: sample 1 starts at slot 24
   }
 
   struct Item { int n, y0, x0, tn; };
