@@ -190,6 +190,7 @@ def main():
             tr.train_step_from_inputs(b0 + a.warmup + a.steps + i, inp)
         torch.cuda.synchronize()
     prof = ops.Profile.stop()
+    losses = {k: float(v.item()) for k, v in tr.losses.items()}  # of the last TIMED step (before the graph-replay leg below)
     graph_ms = None
     profiled = any("rocprof" in (os.environ.get(k) or "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
     if world == 1 and not a.graph and a.workload == "c3" and not a.no_graph_leg and not profiled:
@@ -209,7 +210,6 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    losses = {k: float(v.item()) for k, v in tr.losses.items()}
 
     if rank == 0:
         ms = dt / a.steps * 1e3
