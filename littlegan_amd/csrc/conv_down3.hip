@@ -157,7 +157,22 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   auto commit = [&](char* buf, const u32x4 (&v)[PPT]) {
 #pragma unroll
     for (int u = 0; u < PPT; ++u)
-      if (pl[u] >= 0) *reinterpret_cast<u32x4*>(buf + pl[u]) = v[u];
+      if (pl[u] >= 0) {
+        u32x4 w = v[u];
+        if constexpr ((DBG & 16) != 0) {  // probe: the VALU cost of InstanceNorm + LeakyReLU applied while staging (norm.hip apply16 arithmetic)
+          const float mu = p.nf.alpha, mul = 0.001f, na = 1.01f, nb = 0.02f, al = 0.3f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float t0 = __builtin_bit_cast(float, w[k] << 16), t1 = __builtin_bit_cast(float, w[k] & 0xffff0000u);
+            t0 = na * ((t0 - mu) - mul) + nb; t1 = na * ((t1 - mu) - mul) + nb;
+            t0 = fmaxf(t0, al * t0); t1 = fmaxf(t1, al * t1);
+            const __bf16 h0 = (__bf16)t0, h1 = (__bf16)t1;
+            const unsigned o = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            w[k] = pyx[u] != (0x7fff << 8) ? o : 0u;
+          }
+        }
+        *reinterpret_cast<u32x4*>(buf + pl[u]) = w;
+      }
   };
   // weight fragment of (tap t, column tile tn, k-step kb) for this wave's 32 columns
   const unsigned lane16 = lane * 16;
