@@ -12,6 +12,7 @@
 //   up_p16      : dimg[B,2H,2W,3] = conv2d_backprop_input(dz16[B,H,W,C])  (gradient of Encoder.conv1, model.py:15)
 // Weights come from the verbatim fp32 copy in the pack (pack.hip, cb == 3) and are rounded to bf16 (RNE) here, the
 // same rounding the packed MFMA operands get; accumulation is fp32 throughout.
+#include <stdlib.h>
 #include "lg_common.h"
 
 namespace {
@@ -202,22 +203,42 @@ __global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict_
   for (int nt = 0; nt < NT; ++nt) bv[nt] = bias ? bias[nt * 16 + r] : 0.f;
   for (int i = HSIDE * ROWF + threadIdx.x; i < TROWS * ROWF + 4; i += 256) tile[i] = 0.f;  // rows the zero-weight slots touch
 
+  // the halo of the NEXT tile is requested (global -> registers) before this tile's MFMAs and written to LDS behind them:
+  // the block no longer sits out a global-memory latency per tile (measured: 66-71 % of the wave cycles were parked)
+  constexpr int NPT = (HSIDE * HSIDE + 255) / 256;  // halo pixels per thread
+  float hv[NPT][3];
+  auto halo_load = [&](int t) {
+    const int n = t / tpi, tt = t - n * tpi;
+    const int y0 = (tt / tpx) * TS, x0 = (tt % tpx) * TS;
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+      const int i = threadIdx.x + u * 256, hy = i / HSIDE, hx = i - hy * HSIDE;
+      const int sy = S * y0 - pad + hy, sx = S * x0 - pad + hx;
+      hv[u][0] = 0.f; hv[u][1] = 0.f; hv[u][2] = 0.f;
+      if (i < HSIDE * HSIDE && (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws) {
+        const float* q = src + ((long long)(n * Hs + sy) * Ws + sx) * 3;
+        hv[u][0] = q[0]; hv[u][1] = q[1]; hv[u][2] = q[2];
+      }
+    }
+  };
+  auto halo_store = [&]() {
+#pragma unroll
+    for (int u = 0; u < NPT; ++u) {
+      const int i = threadIdx.x + u * 256;
+      if (i < HSIDE * HSIDE) {
+        float* d = tile + i * 3;
+        d[0] = hv[u][0]; d[1] = hv[u][1]; d[2] = hv[u][2];
+      }
+    }
+  };
+  if ((int)blockIdx.x < ntiles) halo_load(blockIdx.x);
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int n = t / tpi, tt = t - n * tpi;
     const int y0 = (tt / tpx) * TS, x0 = (tt % tpx) * TS;
     __syncthreads();  // previous tile fully consumed
-    for (int i = threadIdx.x; i < HSIDE * HSIDE; i += 256) {
-      const int hy = i / HSIDE, hx = i - hy * HSIDE;
-      const int sy = S * y0 - pad + hy, sx = S * x0 - pad + hx;
-      float a = 0.f, b = 0.f, c = 0.f;
-      if ((unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws) {
-        const float* q = src + ((long long)(n * Hs + sy) * Ws + sx) * 3;
-        a = q[0]; b = q[1]; c = q[2];
-      }
-      float* d = tile + (hy * HSIDE + hx) * 3;
-      d[0] = a; d[1] = b; d[2] = c;
-    }
+    halo_store();
     __syncthreads();
+    if (t + (int)gridDim.x < ntiles) halo_load(t + gridDim.x);
 
     // one m-tile (a tile row of 16 pixels) at a time: MFMAs -> + bias -> moments -> wave-private LDS transpose -> whole
     // contiguous rows out, 16 B per lane.  No block barrier in here: LDS operations of one wave execute in order.
@@ -324,6 +345,22 @@ extern "C" int lg_n3_up_p16_try(const void* src16, const float* w, float* out, i
   return LG_OK;
 }
 
+// persistent grid of the patch kernels: a block sets up 12-24 weight fragments (8 converted weights each per lane) and then
+// walks its tiles with the next halo in flight, so it should own several tiles; 3 blocks fit a CU (160 VGPRs)
+static int patch_grid(int ntiles, int per_cu) {  // per_cu: resident blocks per CU of the instantiation (VGPR-limited)
+  static int cus = 0, forced = -1;
+  if (!cus) {
+    const char* e = getenv("LG_PATCH_GRID");
+    forced = e ? atoi(e) : 0;
+    int dev = 0;
+    hipDeviceProp_t pr;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+  }
+  const int nb = forced > 0 ? forced : per_cu * cus;
+  return ntiles < nb ? ntiles : nb;
+}
+
 extern "C" int lg_n3_conv1_p16_supported(int H, int W, int N) { return (H % TS == 0 && W % TS == 0 && N == 64) ? 1 : 0; }
 
 // conv1 forward from the fp32 image (bf16 MFMA), with the per-block InstanceNorm moments; *nparts = records per sample
@@ -333,7 +370,7 @@ extern "C" int lg_n3_conv1_fwd_p16_try(const float* img, const float* w, const f
   if (H % TS || W % TS || N != 64 || !img || !w || (!z && !z16)) return LG_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int tpi = (H / TS) * (W / TS), ntiles = B * tpi;
-  const dim3 grid(ntiles < 4096 ? ntiles : 4096);
+  const dim3 grid(patch_grid(ntiles, 3));  // 160 VGPRs: 3 blocks per CU (measured 4096 / 2048 / 1024 / 768 / 512 blocks: 93 / 75 / 72 / 59 / 66 us)
   const bool stats = spart && nparts && (size_t)B * tpi * 3 * sizeof(double) <= spart_bytes;
   if (z16) {  // bf16 activation path: z leaves as bf16 (the moments still come from the fp32 accumulators)
     if (stats) hipLaunchKernelGGL((patch_p16_kernel<2, 64, true, true>), grid, dim3(256), 0, st, img, w, bias, nullptr, (__bf16*)z16, (double*)spart, B, H, W, 1);
@@ -360,7 +397,7 @@ extern "C" int lg_n3_s1_dgrad_p16_nf_try(const float* dpre, const float* w, floa
   hipStream_t st = (hipStream_t)stream;
   const int tpi_ = (H / TS) * (W / TS);
   const int ntiles = B * tpi_;
-  const dim3 grid(ntiles < 4096 ? ntiles : 4096);
+  const dim3 grid(patch_grid(ntiles, 4));  // 80-104 VGPRs (measured with the fused sums: 168 / 154 / 146 / 161 / 200 us)
   if (dx16 && nf && nf->z && nf->stats && nf->part && nparts_out && (size_t)B * tpi_ * 2 * sizeof(double) <= nf_bytes) {
     hipLaunchKernelGGL((patch_p16_kernel<1, 32, true, false, true>), grid, dim3(256), 0, st, dpre, w, nullptr, nullptr, (__bf16*)dx16, nullptr, B, H, W, 2, *nf);
     LG_CHECK_LAUNCH("lg_n3_s1_dgrad_p16(nf)");
