@@ -102,58 +102,76 @@ __global__ __launch_bounds__(256) void up_p16_kernel(const __bf16* __restrict__ 
   constexpr int HS = TS + 2, NQ = HS * HS, NMT = (NQ + 15) / 16, MTW = (NMT + 3) / 4, KH = C / 32;
   __shared__ float sP[NMT * 16 * PR];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
-  const int tpx = W / TS, tpi = tpx * (H / TS);
-  const int n = blockIdx.x / tpi, tt = blockIdx.x % tpi;
-  const int y0 = (tt / tpx) * TS, x0 = (tt % tpx) * TS;
+  const int tpx = W / TS, tpi = tpx * (H / TS), ntiles = B * tpi, G = gridDim.x;
 
-  bf16x8 bf[5][KH], af[MTW][KH];
-#pragma unroll
-  for (int i = 0; i < MTW; ++i) {
-    const int mt = wid + 4 * i, q = mt * 16 + r;
-    const int sy = y0 - 1 + q / HS, sx = x0 - 1 + q % HS;
-    const bool ok = q < NQ && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
-#pragma unroll
-    for (int kh = 0; kh < KH; ++kh)
-      af[i][kh] = ok ? *reinterpret_cast<const bf16x8*>(src16 + ((long long)(n * H + sy) * W + sx) * C + kh * 32 + g * 8) : zero8();
-  }
+  // persistent: the 5 x KH weight fragments (8 converted weights each per lane) are set up once per block, and the A
+  // fragments of the block's NEXT tile are requested before this tile's passes (two register sets, loop unrolled by two)
+  bf16x8 bf[5][KH];
   load_bfrags<C>(w, lane, bf);
-
-  const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
-  float acc[4][3];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { acc[k][0] = 0.f; acc[k][1] = 0.f; acc[k][2] = 0.f; }
-#pragma unroll
-  for (int ky = 0; ky < 5; ++ky) {
+  auto load_af = [&](int t, bf16x8 (&af)[MTW][KH]) {
+    const int n = t / tpi, tt = t - n * tpi;
+    const int y0 = (tt / tpx) * TS, x0 = (tt % tpx) * TS;
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
-      const int mt = wid + 4 * i;
-      if (mt < NMT) {
-        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+      const int mt = wid + 4 * i, q = mt * 16 + r;
+      const int sy = y0 - 1 + q / HS, sx = x0 - 1 + q % HS;
+      const bool ok = q < NQ && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
 #pragma unroll
-        for (int kh = 0; kh < KH; ++kh) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kh], bf[ky][kh], c, 0, 0, 0);
+      for (int kh = 0; kh < KH; ++kh)
+        af[i][kh] = ok ? *reinterpret_cast<const bf16x8*>(src16 + ((long long)(n * H + sy) * W + sx) * C + kh * 32 + g * 8) : zero8();
+    }
+  };
+  const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
+  auto compute = [&](int t, const bf16x8 (&af)[MTW][KH]) {
+    const int n = t / tpi, tt = t - n * tpi;
+    const int y0 = (tt / tpx) * TS, x0 = (tt % tpx) * TS;
+    float acc[4][3];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sP[(mt * 16 + 4 * g + e) * PR + r] = c[e];
+    for (int k = 0; k < 4; ++k) { acc[k][0] = 0.f; acc[k][1] = 0.f; acc[k][2] = 0.f; }
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) {
+        const int mt = wid + 4 * i;
+        if (mt < NMT) {
+          f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kh = 0; kh < KH; ++kh) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kh], bf[ky][kh], c, 0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sP[(mt * 16 + 4 * g + e) * PR + r] = c[e];
+        }
       }
+      __syncthreads();
+      // out[2q+p] += src[q + d] W[k],  p = 1 - (k & 1),  d = (p + 1 - k) / 2   (conv2d_backprop_input, SAME, s=2, k=5)
+      const int py = 1 - (ky & 1), dy = (py + 1 - ky) / 2;
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) {
+        const int px = 1 - (kx & 1), dx = (px + 1 - kx) / 2;
+        const float* pp = sP + ((ly + 1 + dy) * HS + (lx + 1 + dx)) * PR + kx * 3;
+        acc[py * 2 + px][0] += pp[0]; acc[py * 2 + px][1] += pp[1]; acc[py * 2 + px][2] += pp[2];
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    // out[2q+p] += src[q + d] W[k],  p = 1 - (k & 1),  d = (p + 1 - k) / 2   (conv2d_backprop_input, SAME, s=2, k=5)
-    const int py = 1 - (ky & 1), dy = (py + 1 - ky) / 2;
+    const int yq = y0 + ly, xq = x0 + lx;
 #pragma unroll
-    for (int kx = 0; kx < 5; ++kx) {
-      const int px = 1 - (kx & 1), dx = (px + 1 - kx) / 2;
-      const float* pp = sP + ((ly + 1 + dy) * HS + (lx + 1 + dx)) * PR + kx * 3;
-      acc[py * 2 + px][0] += pp[0]; acc[py * 2 + px][1] += pp[1]; acc[py * 2 + px][2] += pp[2];
+    for (int py = 0; py < 2; ++py) {
+      float* o = out + ((long long)(n * 2 * H + 2 * yq + py) * 2 * W + 2 * xq) * 3;
+#pragma unroll
+      for (int px = 0; px < 2; ++px)
+#pragma unroll
+        for (int co = 0; co < 3; ++co) o[px * 3 + co] = acc[py * 2 + px][co];
     }
-    __syncthreads();
-  }
-  const int yq = y0 + ly, xq = x0 + lx;
-#pragma unroll
-  for (int py = 0; py < 2; ++py) {
-    float* o = out + ((long long)(n * 2 * H + 2 * yq + py) * 2 * W + 2 * xq) * 3;
-#pragma unroll
-    for (int px = 0; px < 2; ++px)
-#pragma unroll
-      for (int co = 0; co < 3; ++co) o[px * 3 + co] = acc[py * 2 + px][co];
+  };
+  bf16x8 afA[MTW][KH], afB[MTW][KH];
+  int t = blockIdx.x;
+  if (t < ntiles) load_af(t, afA);
+  for (; t < ntiles; t += 2 * G) {
+    if (t + G < ntiles) load_af(t + G, afB);
+    compute(t, afA);
+    if (t + G < ntiles) {
+      if (t + 2 * G < ntiles) load_af(t + 2 * G, afA);
+      compute(t + G, afB);
+    }
   }
 }
 
@@ -322,6 +340,22 @@ __global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict_
 }  // namespace
 
 // ---- entry points (LG_ERR_UNSUPPORTED -> the caller falls back to the fp32-source kernels) ----
+// persistent grid of the patch kernels: a block sets up 12-24 weight fragments (8 converted weights each per lane) and then
+// walks its tiles with the next halo in flight, so it should own several tiles; 3 blocks fit a CU (160 VGPRs)
+static int patch_grid(int ntiles, int per_cu) {  // per_cu: resident blocks per CU of the instantiation (VGPR-limited)
+  static int cus = 0, forced = -1;
+  if (!cus) {
+    const char* e = getenv("LG_PATCH_GRID");
+    forced = e ? atoi(e) : 0;
+    int dev = 0;
+    hipDeviceProp_t pr;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+  }
+  const int nb = forced > 0 ? forced : per_cu * cus;
+  return ntiles < nb ? ntiles : nb;
+}
+
 extern "C" int lg_n3_p16_supported(int H, int W, int C) { return (H % TS == 0 && W % TS == 0 && (C == 32 || C == 64)) ? 1 : 0; }
 
 extern "C" int lg_n3_s1t_fwd_p16_try(const void* x16, const float* w, const float* bias, float* y, int B, int H, int W,
@@ -338,27 +372,11 @@ extern "C" int lg_n3_s1t_fwd_p16_try(const void* x16, const float* w, const floa
 extern "C" int lg_n3_up_p16_try(const void* src16, const float* w, float* out, int B, int H, int W, int C, void* stream) {
   if (!lg_n3_p16_supported(H, W, C) || !src16 || !w) return LG_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(B * (H / TS) * (W / TS));
+  const dim3 grid(patch_grid(B * (H / TS) * (W / TS), 2));  // 228-244 VGPRs: 2 blocks per CU (measured 4096 / 1024 / 768 / 512 blocks: 96 / 63 / 77 / 55 us)
   if (C == 32) hipLaunchKernelGGL(up_p16_kernel<32>, grid, dim3(256), 0, st, (const __bf16*)src16, w, out, B, H, W);
   else hipLaunchKernelGGL(up_p16_kernel<64>, grid, dim3(256), 0, st, (const __bf16*)src16, w, out, B, H, W);
   LG_CHECK_LAUNCH("lg_n3_up_p16");
   return LG_OK;
-}
-
-// persistent grid of the patch kernels: a block sets up 12-24 weight fragments (8 converted weights each per lane) and then
-// walks its tiles with the next halo in flight, so it should own several tiles; 3 blocks fit a CU (160 VGPRs)
-static int patch_grid(int ntiles, int per_cu) {  // per_cu: resident blocks per CU of the instantiation (VGPR-limited)
-  static int cus = 0, forced = -1;
-  if (!cus) {
-    const char* e = getenv("LG_PATCH_GRID");
-    forced = e ? atoi(e) : 0;
-    int dev = 0;
-    hipDeviceProp_t pr;
-    cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
-  }
-  const int nb = forced > 0 ? forced : per_cu * cus;
-  return ntiles < nb ? ntiles : nb;
 }
 
 extern "C" int lg_n3_conv1_p16_supported(int H, int W, int N) { return (H % TS == 0 && W % TS == 0 && N == 64) ? 1 : 0; }
