@@ -254,24 +254,47 @@ __global__ __launch_bounds__(256) void n3_wgrad16_kernel(const float* __restrict
   const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
   const int colbase = 16 * (g & 1) + 4 * lp;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // the NEXT tile's operands are requested (global -> registers) before this tile's MFMAs and written to LDS behind them
+  constexpr int NPB = TH * TW * (Cs / 8) / 256;          // 16-B pieces of the wide operand per thread (2 | 4)
+  constexpr int NPA = (20 * 36 * 3 + 255) / 256;         // halo floats per thread, s = 2 (the larger halo): 9
+  u32x4 rb[NPB];
+  float ra[NPA];
+  auto tile_load = [&](int tile) {
     const int n = tile / tpi, tt = tile - n * tpi;
     const int y0 = (tt / tpx) * TH, x0 = (tt % tpx) * TW;
-    __syncthreads();
-    for (int i = threadIdx.x; i < TH * TW * (Cs / 8); i += 256) {
-      const int pix = i / (Cs / 8), c8 = i % (Cs / 8);
+#pragma unroll
+    for (int u = 0; u < NPB; ++u) {
+      const int i = threadIdx.x + u * 256, pix = i / (Cs / 8), c8 = i % (Cs / 8);
       const int yy = y0 + pix / TW, xx = x0 + pix % TW;
-      *reinterpret_cast<u32x4*>(sB + pix * RSB + c8 * 16) =
-          *reinterpret_cast<const u32x4*>(small16 + ((long long)(n * H + yy) * W + xx) * Cs + c8 * 8);
+      rb[u] = *reinterpret_cast<const u32x4*>(small16 + ((long long)(n * H + yy) * W + xx) * Cs + c8 * 8);
     }
-    for (int i = threadIdx.x; i < HH * HW * 3; i += 256) {
-      const int hp = i / 3, c3 = i - hp * 3;
+#pragma unroll
+    for (int u = 0; u < NPA; ++u) {
+      const int i = threadIdx.x + u * 256, hp = i / 3, c3 = i - hp * 3;
       const int sy = s * y0 - pad + hp / HW, sx = s * x0 - pad + hp % HW;
       float v = 0.f;
-      if ((unsigned)sy < (unsigned)Hb && (unsigned)sx < (unsigned)Wb) v = big3[((long long)(n * Hb + sy) * Wb + sx) * 3 + c3];
-      sA[i] = v;
+      if (i < HH * HW * 3 && (unsigned)sy < (unsigned)Hb && (unsigned)sx < (unsigned)Wb) v = big3[((long long)(n * Hb + sy) * Wb + sx) * 3 + c3];
+      ra[u] = v;
     }
+  };
+  auto tile_store = [&]() {
+#pragma unroll
+    for (int u = 0; u < NPB; ++u) {
+      const int i = threadIdx.x + u * 256, pix = i / (Cs / 8), c8 = i % (Cs / 8);
+      *reinterpret_cast<u32x4*>(sB + pix * RSB + c8 * 16) = rb[u];
+    }
+#pragma unroll
+    for (int u = 0; u < NPA; ++u) {
+      const int i = threadIdx.x + u * 256;
+      if (i < HH * HW * 3) sA[i] = ra[u];
+    }
+  };
+  if ((int)blockIdx.x < ntiles) tile_load(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     __syncthreads();
+    tile_store();
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) tile_load(tile + gridDim.x);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ly = 2 * wid + ks;  // tile row = the 16 pixels of this k step
