@@ -5,6 +5,7 @@
 //   n3_s1t_fwd : y[B,H,W,3] = tanh(convT_s1(x[B,H,W,C]) + b)            /root/reference/model.py:86-87,104
 //   n3_up      : dimg[B,2H,2W,3] = conv2d_backprop_input(dz[B,H,W,C])   (gradient of Encoder.conv1, model.py:15)
 //   n3_wgrad   : dW[5][5][3][C] (+)= sum big3[s*o + k - pad][c3] * small[o][c]   (conv1: s=2,pad=1; final: s=1,pad=2)
+#include <stdlib.h>
 #include "lg_common.h"
 
 namespace {
@@ -374,7 +375,12 @@ __global__ __launch_bounds__(256) void n3_slab_reduce_kernel(const float* __rest
 }
 
 // persistent blocks: measured best at 2 per CU for Cs 64 (41 KB LDS; 3 per CU was 30 % slower) and 6 per CU for Cs 32 (19 KB)
-inline int wgrad_blocks(int ntiles, int Cs) { const int cap = Cs > 32 ? 512 : 1536; return ntiles < cap ? ntiles : cap; }
+inline int wgrad_blocks(int ntiles, int Cs) {
+  static int f32 = -1, f64 = -1;
+  if (f32 < 0) { const char* e = getenv("LG_N3W_CAP32"); f32 = e ? atoi(e) : 0; const char* g = getenv("LG_N3W_CAP64"); f64 = g ? atoi(g) : 0; }
+  const int cap = Cs > 32 ? (f64 > 0 ? f64 : 512) : (f32 > 0 ? f32 : 768);  // measured with the prefetch (256..2048): Cs 64: 128 / 82 / 109 / 99 / 113 / 130 us, Cs 32: 320 / 212 / 182 / 214 / 189 / 200 us
+  return ntiles < cap ? ntiles : cap;
+}
 
 }  // namespace
 
