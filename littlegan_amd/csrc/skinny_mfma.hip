@@ -47,22 +47,29 @@ __global__ __launch_bounds__(256) void heads_fwd_mfma_kernel(const float* __rest
   const HeadCol c0 = head_col(wpr, wc, r, c), c1 = head_col(wpr, wc, 32 + r, c);
   const bool two = c >= 32;  // (uniform) the second column tile holds real columns
   f32x16 acc0 = zero16(), acc1 = zero16();
-#pragma unroll 2
-  for (int g = 0; g < 8; ++g) {  // 16 k per trip: this lane owns 8 of them
-    const f32x4 alo = *reinterpret_cast<const f32x4*>(xr + 16 * g), ahi = *reinterpret_cast<const f32x4*>(xr + 16 * g + 4);
-    float w0[8], w1[8];
+  constexpr int GU = 2;  // groups of 16 k per trip (this lane owns 8 of each): 2 GU + 16 GU loads in flight (latency-bound; GU 1 / 2 / 4: 40 / 33 / 34 us at B=256)
+  for (int g2 = 0; g2 < 8; g2 += GU) {
+    f32x4 alo[GU], ahi[GU];
+    float w0[GU][8], w1[GU][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const long long k = kw + 16 * g + e;
-      w0[e] = c0.ok ? c0.ptr[k * c0.stride] : 0.f;
-      w1[e] = (two && c1.ok) ? c1.ptr[k * c1.stride] : 0.f;
+    for (int u = 0; u < GU; ++u) {
+      const int g = g2 + u;
+      alo[u] = *reinterpret_cast<const f32x4*>(xr + 16 * g); ahi[u] = *reinterpret_cast<const f32x4*>(xr + 16 * g + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const long long k = kw + 16 * g + e;
+        w0[u][e] = c0.ok ? c0.ptr[k * c0.stride] : 0.f;
+        w1[u][e] = (two && c1.ok) ? c1.ptr[k * c1.stride] : 0.f;
+      }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float a = e < 4 ? alo[e & 3] : ahi[e & 3];
-      acc0 = mfma2(a, w0[e], acc0);
-      if (two) acc1 = mfma2(a, w1[e], acc1);
-    }
+    for (int u = 0; u < GU; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = e < 4 ? alo[u][e & 3] : ahi[u][e & 3];
+        acc0 = mfma2(a, w0[u][e], acc0);
+        if (two) acc1 = mfma2(a, w1[u][e], acc1);
+      }
   }
 #pragma unroll
   for (int e = 0; e < 16; ++e) { sred[wid][0][e][lane] = acc0[e]; sred[wid][1][e][lane] = acc1[e]; }
@@ -94,17 +101,18 @@ __global__ __launch_bounds__(256) void heads_wgrad_mfma_kernel(const float* __re
   const float* d0 = dz + (long long)(bs + h) * (c + 1) + r;         // B[b = 2 s + h][col r]
   const float* d1 = d0 + 32;
   f32x16 acc0 = zero16(), acc1 = zero16();
-#pragma unroll 2
-  for (int b = 0; b < bq; b += 16) {
-    float a[8], v0[8], v1[8];
+  constexpr int SU = 16;  // contraction steps (sample pairs) per trip: 3 SU loads in flight
+  for (int b = 0; b < bq; b += 2 * SU) {
+    float a[SU], v0[SU], v1[SU];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      a[s] = xp[(long long)(b + 2 * s) * K];
-      v0[s] = ok0 ? d0[(long long)(b + 2 * s) * (c + 1)] : 0.f;
-      v1[s] = (two && ok1) ? d1[(long long)(b + 2 * s) * (c + 1)] : 0.f;
+    for (int s = 0; s < SU; ++s) {
+      const bool ok = b + 2 * s < bq;
+      a[s] = ok ? xp[(long long)(b + 2 * s) * K] : 0.f;
+      v0[s] = (ok && ok0) ? d0[(long long)(b + 2 * s) * (c + 1)] : 0.f;
+      v1[s] = (ok && two && ok1) ? d1[(long long)(b + 2 * s) * (c + 1)] : 0.f;
     }
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < SU; ++s) {
       acc0 = mfma2(a[s], v0[s], acc0);
       if (two) acc1 = mfma2(a[s], v1[s], acc1);
       bs0 += v0[s]; bs1 += v1[s];
@@ -234,17 +242,18 @@ __global__ __launch_bounds__(256) void dense_wgrad_mfma_kernel(const float* __re
   float bsum = 0.f;
   const float* dp = dy + (long long)(bs + h) * N + n;        // B[b = 2 s + h][col]
   const float* xp = x + (long long)(bs + h) * K + r;         // A[row k = 32 m + r][b = 2 s + h]
-#pragma unroll 2
-  for (int b = 0; b < bq; b += 8) {
-    float d[4], a[4][MT];
+  constexpr int SU = 8;  // contraction steps (sample pairs) per trip: (1 + MT) SU loads in flight
+  for (int b = 0; b < bq; b += 2 * SU) {
+    float d[SU], a[SU][MT];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      d[s] = dp[(long long)(b + 2 * s) * N];
+    for (int s = 0; s < SU; ++s) {
+      const bool ok = b + 2 * s < bq;
+      d[s] = ok ? dp[(long long)(b + 2 * s) * N] : 0.f;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a[s][m] = (32 * m + r < K) ? xp[(long long)(b + 2 * s) * K + 32 * m] : 0.f;
+      for (int m = 0; m < MT; ++m) a[s][m] = (ok && 32 * m + r < K) ? xp[(long long)(b + 2 * s) * K + 32 * m] : 0.f;
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < SU; ++s) {
       bsum += d[s];
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[m] = mfma2(a[s][m], d[s], acc[m]);
