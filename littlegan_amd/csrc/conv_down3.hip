@@ -54,6 +54,12 @@ struct D3L {
 #define LG_D3_DBG 0   // compile-time ablation bits (timing only, results wrong): 1 no MFMA, 2 no fragment loads, 4 no halo staging, 8 no epilogue
 #endif
 constexpr int DBG = LG_D3_DBG;
+#ifndef LG_D3_RING
+#define LG_D3_RING 10   // weight-fragment look-ahead in taps (5: one instantiation of the slice body; 10: two, ring offsets 0 / 5)
+#endif
+#ifndef LG_D3_ADEPTH
+#define LG_D3_ADEPTH 2  // A-fragment buffers: 2 = requested one tap ahead, 3 = two taps ahead
+#endif
 
 struct D3Params {
   const __bf16* src;   // [B][Hs][Ws][Cs] bf16
@@ -192,7 +198,8 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   // Weight-fragment ring: RING fragments (= taps) ahead of the MFMAs.  25 taps per slice and RING = 10 -> the ring
   // position of tap 0 alternates between 0 and 5 from one slice to the next: the slice body exists in two copies
   // (OFF = 0 / 5) so that every ring access is a compile-time register.
-  constexpr int RING = 10;
+  constexpr int RING = LG_D3_RING;
+  constexpr int AD = LG_D3_ADEPTH;
   u32x4 bf[RING];
   u32x4 hv[PPT];
 
@@ -243,21 +250,24 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
     // serialises each MFMA behind its own LDS read (measured in the .s: "ds_read; s_waitcnt lgkmcnt(0); v_mfma" per
     // MFMA, "global_load; s_waitcnt vmcnt(0)" per tap).  Per tap: the A fragments of tap t+1 are requested, then the 4
     // MFMAs of tap t issue, then the ring slot they freed is refilled RING taps ahead.
-    bf16x8 a[2][NI];
+    bf16x8 a[AD][NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes<PAIR>(0));
+    for (int d = 0; d + 1 < AD; ++d)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) a[d][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes<PAIR>(d));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) {
-      if (t + 1 < NTAP) {
+      if (t + AD - 1 < NTAP) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) a[(t + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes<PAIR>(t + 1 < NTAP ? t + 1 : 0));
+        for (int i = 0; i < NI; ++i)
+          a[(t + AD - 1) % AD][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes<PAIR>(t + AD - 1 < NTAP ? t + AD - 1 : 0));
       }
       __builtin_amdgcn_sched_barrier(0);
       const int slot = (t + OFF) % RING;
 #pragma unroll
       for (int i = 0; i < NI; ++i)  // transposed product: rows = this wave's 32 output channels, columns = 32 pixels
-        if constexpr (!(DBG & 1)) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[slot]), a[t & 1][i], acc[i], 0, 0, 0);
+        if constexpr (!(DBG & 1)) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[slot]), a[t % AD][i], acc[i], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       // the slot is free: request the fragment RING taps ahead (this slice, or the next one)
       if constexpr (!(DBG & 2)) {
@@ -405,9 +415,13 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
     cur = nxt;
     c = c2;
   };
-  for (int s = 0; s < total; s += 2) {
-    slice(std::integral_constant<int, 0>{}, s);
-    if (s + 1 < total) slice(std::integral_constant<int, NTAP % RING>{}, s + 1);
+  if constexpr (NTAP % RING == 0) {
+    for (int s = 0; s < total; ++s) slice(std::integral_constant<int, 0>{}, s);  // ONE instantiation of the slice body
+  } else {
+    for (int s = 0; s < total; s += 2) {
+      slice(std::integral_constant<int, 0>{}, s);
+      if (s + 1 < total) slice(std::integral_constant<int, NTAP % RING>{}, s + 1);
+    }
   }
 }
 

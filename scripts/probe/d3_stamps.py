@@ -14,6 +14,13 @@ bias = torch.zeros(128, device="cuda")
 for _ in range(3):
     ops.conv2d_s2_fwd_stats(None, pack, bias, 128, dt, gm, bt, x16=x16, z16=True)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    ops.conv2d_s2_fwd_stats(None, pack, bias, 128, dt, gm, bt, x16=x16, z16=True)
+e1.record()
+torch.cuda.synchronize()
+print(f"kernel time (events, incl. the stats-final launch): {e0.elapsed_time(e1) / 10 * 1e3:.1f} us")
 st = buf.view(512, 64).cpu().numpy()
 t0 = st[:, 0].min()
 for b in (0, 1, 8, 9, 100, 256, 257, 511):
@@ -21,5 +28,7 @@ for b in (0, 1, 8, 9, 100, 256, 257, 511):
     n = int((row > 0).sum())
     d = [int(row[i] - row[i - 1]) for i in range(1, n)]
     print(f"block {b}: start +{int(row[0]-t0)} ; deltas {d}")
+span = float((st.max(1) - st[:, 0]).max())
+print("longest block span (ticks):", span, " all-block span:", float(st.max() - st[:, 0].min()))
 print("first stamps (rel):", sorted((st[:, 0] - t0).tolist())[::64])
 print("last stamps (rel):", sorted((st.max(1) - t0).tolist())[::64])
