@@ -129,7 +129,6 @@ class EagerTrainer:
         if run_adj:
             adj_in_cond = (torch.cat([c2, c1], 0) + 1.0) * 0.5
             adj_t_cond = torch.cat([c2, c1], 0)
-            adj_t_img = torch.cat([img2, img1], 0)
             ctx_a: dict = {}
             # encoder(fake) was computed by D above with the same weights: hand its 4 maps to the Adjuster
             tails = [m[B:] for m in ctx_d["enc_maps"]]  # fp32 maps (f32 path) / bf16 mirrors + the fp32 top map (bf16 path)
@@ -141,7 +140,10 @@ class EagerTrainer:
             ops.bce_heads_loss(p_a, adj_t_cond, soft(1.0), 1.0, 1.0, self.losses["adj"], dz_a, False)
             g_adj = D.backward(ctx_d2, dz_a, need_wgrad=False, need_input_grad=True)
             dpre_a = torch.empty_like(g_adj)
-            ops.l1_tanh_loss(adj_t_img, adj_image, g_adj, dpre_a, self.losses["adj"], a.l1_lambda, True)
+            # target = [img2 ; img1]: one call per half instead of a 2B-image concatenation (lambda / 2 over half the elements is
+            # the same scale, exactly: the element count is a multiple of a power of two)
+            ops.l1_tanh_loss(img2, adj_image[:B], g_adj[:B], dpre_a[:B], self.losses["adj"], 0.5 * a.l1_lambda, True)
+            ops.l1_tanh_loss(img1, adj_image[B:], g_adj[B:], dpre_a[B:], self.losses["adj"], 0.5 * a.l1_lambda, True)
             A.backward_own(ctx_a, dpre_a)
             self.sync.launch("A", self.store, *self.store.model_range("A"))
 
