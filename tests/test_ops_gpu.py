@@ -178,6 +178,24 @@ def test_heads_fwd_dgrad_wgrad(ops, B, K, c):
     assert rel(dbpr, dz[:, 0].sum(0, keepdims=True)) < 1e-5 and rel(dbc, dz[:, 1:].sum(0)) < 1e-5
 
 
+def test_skinny_mfma_weight_gradients_accumulate(ops):
+    """accumulate=True on the fp32-MFMA weight-gradient kernels (aligned shapes): dw += x^T dy on top of what is there, biases too."""
+    rng = np.random.default_rng(11)
+    B, K, N, c = 64, 133, 1024, 40
+    x, dy = r32(rng, B, K), r32(rng, B, N)
+    dw0, db0 = r32(rng, K, N), r32(rng, N)
+    dw, db = dev(dw0), dev(db0)
+    ops.dense_wgrad(dev(x), dev(dy), dw, db, accumulate=True)
+    assert rel(dw, dw0 + x.T @ dy) < 1e-5 and rel(db, db0 + dy.sum(0)) < 1e-5
+    Kh = 1024
+    xh, dz = r32(rng, B, Kh), r32(rng, B, 1 + c)
+    w0, b0, wc0, bc0 = r32(rng, Kh, 1), r32(rng, 1), r32(rng, Kh, c), r32(rng, c)
+    dwpr, dbpr, dwc, dbc = dev(w0), dev(b0), dev(wc0), dev(bc0)
+    ops.heads_wgrad(dev(xh), dev(dz), dwpr, dbpr, dwc, dbc, accumulate=True)
+    assert rel(dwpr, w0 + xh.T @ dz[:, :1]) < 1e-5 and rel(dwc, wc0 + xh.T @ dz[:, 1:]) < 1e-5
+    assert rel(dbpr, b0 + dz[:, 0].sum(0, keepdims=True)) < 1e-5 and rel(dbc, bc0 + dz[:, 1:].sum(0)) < 1e-5
+
+
 def test_bce_heads_loss(ops):
     rng = np.random.default_rng(6)
     B, c = 7, 5
