@@ -403,6 +403,40 @@ def test_final_layer_normalises_while_staging(ops, case):
     assert rel(y, exp) < 3e-5
 
 
+@pytest.mark.parametrize("case", [(2, 8, 8, 32, 128), (4, 8, 8, 64, 256), (3, 8, 8, 32, 128), (1, 8, 16, 32, 64), (2, 16, 16, 32, 64),
+                                  (1, 8, 16, 32, 128)])
+def test_bf16_path_down_kernels_small_shapes(ops, case):
+    """The persistent DOWN kernel (conv_down3.hip) in all its tilings at small shapes, through the bf16-activation entry
+    point (bf16 source mirror -> bf16 z + fused moments): 8 x 8 maps with an even batch = sample-PAIR tiles, an odd batch falls
+    back to conv_halo.hip; N = 64 = the 2 x 2-wave 64-column tiles; N = 128 / 256 = the default.  Against the oracle on the rounded
+    operands; the moments against the fp32 values the kernel rounded."""
+    B, Hm, Wm, Cs, N = case
+    rng = np.random.default_rng(zlib_crc(case) + 7)
+    x, w, b = r32(rng, B, 2 * Hm, 2 * Wm, Cs), r32(rng, 5, 5, Cs, N, scale=0.1), r32(rng, N, scale=0.2)
+    gm, bt = dev(np.array([1.0], dtype=np.float32)), dev(np.array([0.0], dtype=np.float32))
+    x16 = dev(x).to(torch.bfloat16)
+    pack = ops.conv_pack(dev(w), Cs, N, 1)
+    z16, st = ops.conv2d_s2_fwd_stats(None, pack, dev(b), N, 1, gm, bt, x16=x16, z16=True)
+    assert z16.dtype == torch.bfloat16 and st is not None
+    exp = O.conv2d(_bf16_round(x), _bf16_round(w), b, 2)
+    assert rel(z16.float(), exp) < TOL[1]
+    ef = exp.reshape(B, -1)
+    assert rel(st[:, 0].double() + st[:, 4].double(), ef.mean(1)) < 2e-5 and rel(st[:, 1], ef.std(1)) < 2e-5
+    # data gradient of the matching transposed conv (same DOWN contraction) with the norm-backward sums of the layer below
+    g16, np_ = ops.convT_s2_dgrad(None, pack, N, 1, dy16=x16, out_bf16=True, fuse=(z16, st, 0.3))
+    assert rel(g16.float(), O.conv2d(_bf16_round(x), _bf16_round(w), np.zeros(N), 2)) < TOL[1]
+    # the fused sums feed the norm backward: same dz / dgamma / dbeta as the stand-alone first pass
+    outs = []
+    for parts in (np_, None):
+        dgm, dbt = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+        dz16 = torch.empty_like(z16)
+        ops.instnorm_bwd(z16, st, g16, dgm, dbt, 0, 1, 0.3, out16=dz16, want_f32=False, partials=parts)
+        outs.append((dz16.float().cpu().numpy(), dgm.item(), dbt.item()))
+    assert np_ is not None or (B % 2 == 1 and Hm == 8 and Wm == 8)   # only the conv_halo fallback has no fused sums
+    assert np.abs(outs[0][0] - outs[1][0]).max() <= 2e-2 * np.abs(outs[1][0]).max()  # (bf16 output: one rounding step)
+    assert abs(outs[0][1] - outs[1][1]) < 1e-4 * (1 + abs(outs[1][1])) and abs(outs[0][2] - outs[1][2]) < 1e-4 * (1 + abs(outs[1][2]))
+
+
 def zlib_crc(case):
     import zlib
     return zlib.crc32(repr(case).encode())
