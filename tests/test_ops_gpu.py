@@ -437,6 +437,28 @@ def test_bf16_path_down_kernels_small_shapes(ops, case):
     assert abs(outs[0][1] - outs[1][1]) < 1e-4 * (1 + abs(outs[1][1])) and abs(outs[0][2] - outs[1][2]) < 1e-4 * (1 + abs(outs[1][2]))
 
 
+@pytest.mark.parametrize("case", [(2, 16, 16, 32, 64), (2, 4, 32, 32, 64), (2, 8, 8, 64, 128), (3, 8, 8, 64, 128), (1, 16, 32, 64, 64)])
+def test_all_taps_weight_gradient_small_shapes(ops, case):
+    """wgrad_at.hip in its three tilings (16 x 8 strips, 32 x 4 strips, 8 x 8 sample pairs; an odd batch of 8 x 8 maps falls
+    back to the per-tap kernel) from the bf16 mirrors, overwrite and accumulate, against the oracle on the rounded operands."""
+    B, Hm, Wm, cb, cs = case
+    rng = np.random.default_rng(zlib_crc(case) + 3)
+    big, small = r32(rng, B, 2 * Hm, 2 * Wm, cb), r32(rng, B, Hm, Wm, cs)
+    b16, s16 = dev(big).to(torch.bfloat16), dev(small).to(torch.bfloat16)
+    exp = O.conv2d_bwd(_bf16_round(big), np.zeros((5, 5, cb, cs)), _bf16_round(small), 2)[1]
+    dw = torch.full((5, 5, cb, cs), 7.0, device="cuda")
+    ops.conv2d_s2_wgrad(None, None, dw, False, 1, x16=b16, dy16=s16)
+    assert rel(dw, exp) < 3e-5
+    pre = r32(rng, 5, 5, cb, cs)
+    dw2 = dev(pre)
+    ops.conv2d_s2_wgrad(None, None, dw2, True, 1, x16=b16, dy16=s16)
+    assert rel(dw2, pre.astype(np.float64) + exp) < 3e-5
+    # the transposed-conv form: roles of the operands swapped at the call, same contraction
+    dw3 = torch.empty(5, 5, cb, cs, device="cuda")
+    ops.convT_s2_wgrad(None, None, dw3, False, 1, x16=s16, dy16=b16)
+    assert torch.equal(dw3, dw)
+
+
 def zlib_crc(case):
     import zlib
     return zlib.crc32(repr(case).encode())
