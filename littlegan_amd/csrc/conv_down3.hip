@@ -57,6 +57,9 @@ constexpr int DBG = LG_D3_DBG;
 #ifndef LG_D3_RING
 #define LG_D3_RING 10   // weight-fragment look-ahead in taps (5: one instantiation of the slice body; 10: two, ring offsets 0 / 5)
 #endif
+#ifndef LG_D3_SCHED
+#define LG_D3_SCHED 1   // 0: tap body in three pinned groups (A reads | MFMAs | ring refill); 1: interleaved by sched_group_barrier
+#endif
 #ifndef LG_D3_ADEPTH
 #define LG_D3_ADEPTH 2  // A-fragment buffers: 2 = requested one tap ahead, 3 = two taps ahead
 #endif
@@ -263,18 +266,29 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
         for (int i = 0; i < NI; ++i)
           a[(t + AD - 1) % AD][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + toff_bytes<PAIR>(t + AD - 1 < NTAP ? t + AD - 1 : 0));
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (LG_D3_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
       const int slot = (t + OFF) % RING;
 #pragma unroll
       for (int i = 0; i < NI; ++i)  // transposed product: rows = this wave's 32 output channels, columns = 32 pixels
         if constexpr (!(DBG & 1)) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[slot]), a[t % AD][i], acc[i], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (LG_D3_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
       // the slot is free: request the fragment RING taps ahead (this slice, or the next one)
       if constexpr (!(DBG & 2)) {
         if (t + RING < NTAP) bf[slot] = wfrag(wcur, t + RING);
         else bf[slot] = wfrag(wnxt, t + RING - NTAP);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (LG_D3_SCHED == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        // one MFMA, then one LDS read in its shadow (an MFMA holds the vector issue port for 8 of its 32 cycles), ..., the
+        // ring refill behind the last MFMA: the wave never leaves the MFMA pipe idle to issue its loads
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+      }
     }
     D3_STAMP();   // taps done
     commit(smem + ((s + 1) & 1) * HB, hv);

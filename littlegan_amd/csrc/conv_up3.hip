@@ -27,6 +27,9 @@ namespace {
 
 constexpr int TH = 8, TW = 16, HHT = TH + 2, HWT = TW + 2, NPX = HHT * HWT;  // 10 x 18 = 180 halo pixels
 constexpr int RING = 8;
+#ifndef LG_U3_SCHED
+#define LG_U3_SCHED 1   // 0: fragment step in three pinned groups; 1: interleaved by sched_group_barrier (MFMA, LDS read, ...)
+#endif
 
 template <int CS, int N> struct Cfg {
   static constexpr int WN = N / 32;               // column waves per tile (2 | 1)
@@ -206,15 +209,23 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[(f + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(smem + abase[i] + a_off(f + 1 < F ? f + 1 : 0));
       }
-      __builtin_amdgcn_sched_barrier(0);
-      constexpr int dummy = 0; (void)dummy;
+      if constexpr (LG_U3_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
       const int sl = (f + OFF) % RING;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[sl]), a[f & 1][i], acc[i], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (LG_U3_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
       bf[sl] = *reinterpret_cast<const u32x4*>(frag_ptr(cls_c, (f + RING) % F));  // the stream wraps: same weights every tile
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (LG_U3_SCHED == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+      } else {  // one MFMA, one LDS read in its shadow, ..., the ring refill behind the last MFMA (see conv_down3.hip)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
     }
   };
 

@@ -16,6 +16,9 @@
 #include <stdlib.h>
 #include "lg_common.h"
 
+#ifndef LG_WGAT_SCHED
+#define LG_WGAT_SCHED 0   // 0: k step in pinned groups (sched_barrier); 1: interleaved by sched_group_barrier (MFMA, two LDS reads, ...)
+#endif
 #ifndef LG_WGAT_DBG
 #define LG_WGAT_DBG 0   // timing ablations (results wrong): 1 no MFMA, 2 no fragment reads in the k loop, 4 no staging after the first item
 #endif
@@ -181,23 +184,33 @@ __global__ __launch_bounds__(512) void wgrad_at_kernel(const WgAtParams p) {
     a0 = rd_tr(sb + ab[0] + koffA(0));
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (LG_WGAT_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
       const bf16x8 a1 = (LG_WGAT_DBG & 2) ? a0 : rd_tr(sb + ab[1] + koffA(ks)), a2 = (LG_WGAT_DBG & 2) ? a0 : rd_tr(sb + ab[2] + koffA(ks));
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (LG_WGAT_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
       acc[0][0] = at_mfma(a0, b[0], acc[0][0]);
       acc[0][1] = at_mfma(a0, b[1], acc[0][1]);
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (LG_WGAT_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
       bf16x8 bn[2] = {b[0], b[1]}, a0n = a0;
       if (ks + 1 < 8 && !(LG_WGAT_DBG & 2)) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) bn[h] = rd_tr(sb + bb + koffB(ks + 1, h));
         a0n = rd_tr(sb + ab[0] + koffA(ks + 1));
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (LG_WGAT_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
       acc[1][0] = at_mfma(a1, b[0], acc[1][0]);
       acc[1][1] = at_mfma(a1, b[1], acc[1][1]);
       acc[2][0] = at_mfma(a2, b[0], acc[2][0]);
       acc[2][1] = at_mfma(a2, b[1], acc[2][1]);
+      if constexpr (LG_WGAT_SCHED != 0 && (LG_WGAT_DBG & 3) == 0) {
+        // the ten transposed reads of the step (a1, a2; then b0', b1', a0' of the next one) go two by two into the shadows of
+        // the MFMAs: an MFMA holds the vector issue port for 8 of its 32 cycles
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
       if (wid == ks) {
         const bf16x8 a3 = rd_tr(sb + a24 + koffA(ks));
 #pragma unroll
