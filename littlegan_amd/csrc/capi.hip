@@ -155,6 +155,9 @@ extern "C" int lg_convT_s2_dgrad_m16(const float* dy, const void* dy16, const vo
 extern "C" int lg_conv_up3_nf_try(const void* src16, const void* wpack_up, const float* bias, void* out16, int B, int Hm, int Wm,
                                   int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, const LgNormFuse* nf,
                                   size_t nf_bytes, void* stream);
+extern "C" int lg_conv_up4_nf_try(const void* src16, const void* wpack_up, const float* bias, void* out16, int B, int Hm, int Wm,
+                                  int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, const LgNormFuse* nf,
+                                  size_t nf_bytes, void* stream);
 extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const float* bias, void* out16, int B, int Hm, int Wm,
                                     int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, const LgNormFuse* nf,
                                     size_t nf_bytes, void* stream);
@@ -168,8 +171,12 @@ extern "C" int lg_conv2d_s2_dgrad_nf(const void* dy16, const void* pack, void* d
   *nparts = 0;
   if (cb != 3 && z16 && stats && part && n3_enabled()) {
     LgNormFuse nf{(const __bf16*)z16, stats, (double*)part, alpha, 0};
-    const int rc = lg_conv_up3_nf_try(dy16, up_pack(pack, cb, cs, LG_DT_BF16), nullptr, dx16, B, Hs, Ws, cs, cb, nullptr, 0, nparts,
-                                      &nf, part_bytes, stream);
+    int rc = lg_conv_up3_nf_try(dy16, up_pack(pack, cb, cs, LG_DT_BF16), nullptr, dx16, B, Hs, Ws, cs, cb, nullptr, 0, nparts,
+                                &nf, part_bytes, stream);
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+    *nparts = 0;
+    rc = lg_conv_up4_nf_try(dy16, up_pack(pack, cb, cs, LG_DT_BF16), nullptr, dx16, B, Hs, Ws, cs, cb, nullptr, 0, nparts, &nf,
+                            part_bytes, stream);
     if (rc != LG_ERR_UNSUPPORTED) return rc;
     *nparts = 0;
   }

@@ -352,6 +352,8 @@ extern "C" int lg_npad(int n) {
 extern "C" int lg_conv_igemm_ex(int mode, int dtype, const float* src, const void* src16, const void* wpack,
                                 const float* bias, float* out, void* out16, int B, int Hm, int Wm, int Cs, int N, int act,
                                 int pstride, int ppad, void* spart, size_t spart_bytes, int* nparts_out, void* stream);
+extern "C" int lg_conv_up4_try(const void* src16, const void* wpack_up, const float* bias, void* out16, int B, int Hm, int Wm,
+                               int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, void* stream);
 extern "C" int lg_conv_up3_try(const void* src16, const void* wpack_up, const float* bias, void* out16, int B, int Hm, int Wm,
                                int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, void* stream);
 extern "C" int lg_conv_down3_try(const void* src16, const void* wpack, const float* bias, void* out16, int B, int Hm, int Wm,
@@ -389,6 +391,9 @@ extern "C" int lg_conv_igemm_ex(int mode, int dtype, const float* src, const voi
   if (mode == MODE_UP && dtype == LG_DT_BF16 && src16 && out16 && act == 0 && halo_enabled()) {
     // resident-halo persistent kernel with the four parity classes on concurrent waves (conv_up3.hip): small-N layers
     rc = lg_conv_up3_try(src16, wpack, bias, out16, B, Hm, Wm, Cs, N, spart, spart_bytes, nparts_out, stream);
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+    // the wide layers (N % 128 == 0) on 8 x 16 source tiles: blocks bound to one parity class (conv_up4.hip)
+    rc = lg_conv_up4_try(src16, wpack, bias, out16, B, Hm, Wm, Cs, N, spart, spart_bytes, nparts_out, stream);
     if (rc != LG_ERR_UNSUPPORTED) return rc;
   }
   if (mode != MODE_PATCH && halo_enabled()) {  // LDS halo-tile kernel where the tiling covers the shape

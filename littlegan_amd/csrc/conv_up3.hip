@@ -441,7 +441,9 @@ extern "C" int lg_conv_up3_nf_try(const void* src16, const void* wpack_up, const
 #ifdef LG_U3_STAMPS
   { const char* e = getenv("LG_U3_STAMPBUF"); p.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
-  const bool fuse = nf && nf->z && nf->stats && nf->part && nparts_out && (size_t)B * p.tpi * 2 * sizeof(double) <= nf_bytes;
+  // the norm-backward sums are produced by the (128, 64) form only: with two tiles per step (N = 32) a thread's row sweep covers
+  // both tiles, i.e. possibly two samples, and the per-thread sums would mix them (no layer of the step asks for that form)
+  const bool fuse = Cs == 128 && nf && nf->z && nf->stats && nf->part && nparts_out && (size_t)B * p.tpi * 2 * sizeof(double) <= nf_bytes;
   const bool stats = !fuse && spart && nparts_out && (size_t)B * p.tpi * 3 * sizeof(double) <= spart_bytes;
   p.spart = stats ? (double*)spart : nullptr;
   if (fuse) p.nf = *nf;

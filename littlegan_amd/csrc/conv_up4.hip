@@ -169,20 +169,23 @@ __device__ __forceinline__ void up4_run(const U4Params& p, char* smem, int lb, i
 #pragma unroll
     for (int f = 0; f < F; ++f) {
       if (f + 1 < F) {
-        constexpr int dummy = 0; (void)dummy;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           a[(f + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + tap_aoff(CLS, (f + 1 < F ? f + 1 : 0) / KS) + ((f + 1) % KS) * 32);
       }
-      __builtin_amdgcn_sched_barrier(0);
       const int slot = (f + OFF) % RING;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[slot]), a[f & 1][i], acc[i], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
       if (f + RING < F) bf[slot] = wfrag(wcur, tap_widx(CLS, (f + RING < F ? f + RING : 0) / KS), (f + RING) % KS);
       else bf[slot] = wfrag(wnxt, tap_widx(CLS, (f + RING >= F ? f + RING - F : 0) / KS), (f + RING - F) % KS);
-      __builtin_amdgcn_sched_barrier(0);
+      // one MFMA, one LDS read in its shadow, ..., the ring refill behind the last MFMA (conv_down3.hip)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
     commit(smem + ((s + 1) & 1) * HB, hv);
     __syncthreads();  // slice s consumed by every wave, slice s+1 complete

@@ -437,6 +437,36 @@ def test_bf16_path_down_kernels_small_shapes(ops, case):
     assert abs(outs[0][1] - outs[1][1]) < 1e-4 * (1 + abs(outs[1][1])) and abs(outs[0][2] - outs[1][2]) < 1e-4 * (1 + abs(outs[1][2]))
 
 
+@pytest.mark.parametrize("case", [(2, 8, 16, 64, 128), (1, 16, 16, 128, 256), (2, 8, 16, 128, 64), (2, 8, 16, 64, 32)])
+def test_bf16_path_up_kernels_small_shapes(ops, case):
+    """The persistent UP kernels at small shapes through the bf16-activation entry points: conv_up4.hip (N % 128 == 0: blocks
+    bound to one parity class) and conv_up3.hip ((128, 64) and (64, 32)): transposed-conv forward with fused moments, and the
+    conv data gradient (same contraction, no bias) with the norm-backward sums of the layer below."""
+    B, Hs, Ws, Cs, N = case
+    rng = np.random.default_rng(zlib_crc(case) + 9)
+    x, w, b = r32(rng, B, Hs, Ws, Cs), r32(rng, 5, 5, N, Cs, scale=0.1), r32(rng, N, scale=0.2)
+    gm, bt = dev(np.array([1.0], dtype=np.float32)), dev(np.array([0.0], dtype=np.float32))
+    x16 = dev(x).to(torch.bfloat16)
+    pack = ops.conv_pack(dev(w), N, Cs, 1)
+    z16, st = ops.convT_s2_fwd_stats(None, pack, dev(b), N, 1, gm, bt, x16=x16, z16=True)
+    assert z16.dtype == torch.bfloat16 and st is not None
+    exp = O.conv2d_transpose(_bf16_round(x), _bf16_round(w), b, 2)
+    assert rel(z16.float(), exp) < TOL[1]
+    ef = exp.reshape(B, -1)
+    assert rel(st[:, 0].double() + st[:, 4].double(), ef.mean(1)) < 2e-5 and rel(st[:, 1], ef.std(1)) < 2e-5
+    g16, np_ = ops.conv2d_s2_dgrad(None, pack, N, 1, dy16=x16, out_bf16=True, fuse=(z16, st, 0.3))
+    assert (np_ is not None) == (N != 32)   # the two-tiles-per-step (64, 32) form does not produce the sums
+    assert rel(g16.float(), O.conv2d_transpose(_bf16_round(x), _bf16_round(w), np.zeros(N), 2)) < TOL[1]
+    outs = []
+    for parts in (np_, None):
+        dgm, dbt = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+        dz16 = torch.empty_like(z16)
+        ops.instnorm_bwd(z16, st, g16, dgm, dbt, 0, 1, 0.3, out16=dz16, want_f32=False, partials=parts)
+        outs.append((dz16.float().cpu().numpy(), dgm.item(), dbt.item()))
+    assert np.abs(outs[0][0] - outs[1][0]).max() <= 2e-2 * np.abs(outs[1][0]).max()
+    assert abs(outs[0][1] - outs[1][1]) < 1e-4 * (1 + abs(outs[1][1])) and abs(outs[0][2] - outs[1][2]) < 1e-4 * (1 + abs(outs[1][2]))
+
+
 @pytest.mark.parametrize("case", [(2, 16, 16, 32, 64), (2, 4, 32, 32, 64), (2, 8, 8, 64, 128), (3, 8, 8, 64, 128), (1, 16, 32, 64, 64)])
 def test_all_taps_weight_gradient_small_shapes(ops, case):
     """wgrad_at.hip in its three tilings (16 x 8 strips, 32 x 4 strips, 8 x 8 sample pairs; an odd batch of 8 x 8 maps falls
