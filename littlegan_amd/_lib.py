@@ -103,6 +103,14 @@ def load():
         raise LittleGanHipError(
             f"{LIB_PATH} not found: build it with `python -m littlegan_amd.csrc.build` "
             "(the LittleGAN hot path has no CPU fallback)")
+    # a library linked from objects built with ablation macros (LG_EXTRA_FLAGS of scripts/probe/*.sh: "results wrong, timing
+    # only") must never serve a test, a bench or a training run by accident
+    from .csrc import build as _build
+    fl = _build.built_flags()
+    if fl is not None and fl != " ".join(_build.FLAGS) and not os.environ.get("LG_ALLOW_PROBE_BUILD"):
+        raise LittleGanHipError(
+            f"{LIB_PATH} was built with non-default flags ({fl!r}): a probe / ablation build.  Rebuild with "
+            "`python -m littlegan_amd.csrc.build` (no LG_EXTRA_FLAGS), or set LG_ALLOW_PROBE_BUILD=1 for a timing probe")
     # torch first: it ships its own libamdhip64 and must be the HIP runtime of the process.  If this library were loaded
     # before torch, the system runtime it links against would come in as a SECOND runtime and its kernels would see no device.
     import torch  # noqa: F401

@@ -24,24 +24,45 @@ def build(force=False, verbose=True):
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(HERE, "lg_common.h"), os.path.join(os.path.dirname(PKG), "include", "littlegan_hip.h")]
 
+    # LG_EXTRA_FLAGS carries the ablation macros of scripts/probe/*.sh ("results wrong, timing only"): the flag set an object
+    # was built with is recorded beside it, and an object (hence the library) built with OTHER flags is stale — a probe build
+    # can never be picked up silently by the next test / bench / training run.
+    flags = FLAGS + os.environ.get("LG_EXTRA_FLAGS", "").split()
+    flag_line = " ".join(flags)
+
     def cc(src):
         s = os.path.join(HERE, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + os.environ.get("LG_EXTRA_FLAGS", "").split() + ["-c", s, "-o", o]
+        fl = o + ".flags"
+        same_flags = os.path.exists(fl) and open(fl).read() == flag_line
+        if force or not same_flags or _stale(o, [s] + hdrs):
+            cmd = [hipcc] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
+            if os.path.exists(fl):
+                os.remove(fl)
             subprocess.run(cmd, check=True)
+            with open(fl, "w") as f:
+                f.write(flag_line)
         return o
 
     with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(cc, SOURCES))
-    if force or _stale(LIB, objs):
+    lib_fl = os.path.join(objdir, "lib.flags")
+    if force or _stale(LIB, objs) or not (os.path.exists(lib_fl) and open(lib_fl).read() == flag_line):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        with open(lib_fl, "w") as f:
+            f.write(flag_line)
     return LIB
+
+
+def built_flags():
+    """The flag line the in-tree library was linked from (None if unknown) — _lib.load() refuses a probe build."""
+    p = os.path.join(HERE, "build", "lib.flags")
+    return open(p).read() if os.path.exists(p) else None
 
 
 if __name__ == "__main__":

@@ -703,6 +703,10 @@ extern "C" int lg_instnorm_leaky_bwd_z16_p(const void* z16, const float* stats, 
   LG_CHECK_ARG(B > 0 && B <= 65535 && L > 0 && L % 8 == 0 && (long long)B * L / 8 < (1LL << 31),
                "lg_instnorm_leaky_bwd_z16: bad shape B=%d L=%lld", B, L);
   LG_CHECK_ARG(ws_bytes >= lg_instnorm_workspace_bytes(B, L), "lg_instnorm_leaky_bwd_z16: workspace too small");
+  // producer-fused sums (lg_nf_accum, lg_common.h) are those of the post-LeakyReLU form only; the caller must pass the alpha
+  // the producer used (the record carries none)
+  LG_CHECK_ARG(!(partials && nparts_in > 0) || (pre_leaky == 0 && post_leaky == 1),
+               "lg_instnorm_leaky_bwd_z16_p: fused partial sums exist for pre_leaky=0, post_leaky=1 only (got %d, %d)", pre_leaky, post_leaky);
   if (db) {
     LG_CHECK_ARG(C > 0 && C % 8 == 0 && C / 8 <= 256 && L % C == 0 && (256 % (C / 8) == 0 || 768 % (C / 8) == 0),
                  "lg_instnorm_leaky_bwd_z16: unsupported channel count C=%d (L=%lld)", C, L);

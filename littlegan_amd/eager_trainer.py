@@ -192,9 +192,14 @@ class EagerTrainer:
             g = torch.cuda.CUDAGraph()
             if self._graph_pool is None:
                 self._graph_pool = torch.cuda.graph_pool_handle()
-            ops.Profile.enabled = False
-            with torch.cuda.graph(g, pool=self._graph_pool):   # records the launches, executes nothing
-                out = self.train_step_from_inputs(batch_no, self._graph_in)
+            # the graph records the raw addresses of ops.workspace() buffers: from here on an outgrown buffer is retired, not freed
+            ops.pin_workspaces()
+            prof_was, ops.Profile.enabled = ops.Profile.enabled, False   # HIP events cannot sit inside a captured graph
+            try:
+                with torch.cuda.graph(g, pool=self._graph_pool):   # records the launches, executes nothing
+                    out = self.train_step_from_inputs(batch_no, self._graph_in)
+            finally:
+                ops.Profile.enabled = prof_was
             self._graphs[kind] = (g, out)
         g, out = self._graphs[kind]
         g.replay()

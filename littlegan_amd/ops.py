@@ -12,6 +12,8 @@ from . import _lib
 from ._lib import DT_BF16, DT_F32, check
 
 _WS = {}
+_WS_RETIRED = []     # buffers replaced by a bigger one after a HIP graph captured their address: kept alive for the replays
+_WS_PINNED = False   # set by pin_workspaces() (EagerTrainer.graph_step) as soon as any graph holds workspace pointers
 NSTAT = 8  # floats per sample in the instance-norm statistics record (lg_instnorm_stats_stride)
 
 
@@ -69,11 +71,24 @@ def _chk(t, shape=None, name="tensor"):
     return t
 
 
+def pin_workspaces():
+    """Call before a HIP-graph capture: a captured graph holds the RAW addresses of the scratch buffers below, so from now on
+    a buffer that is outgrown is retired (kept allocated) instead of being handed back to the caching allocator, where a
+    later tensor could land under a replaying graph's writes."""
+    global _WS_PINNED
+    _WS_PINNED = True
+
+
 def workspace(nbytes: int, device, tag="default") -> torch.Tensor:
     """Grow-only scratch buffer per (device, tag); kernels on one stream run in order so sharing is safe."""
     key = (str(device), tag)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and _WS_PINNED:
+            _WS_RETIRED.append(buf)
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.LittleGanHipError(f"workspace '{tag}' must grow to {nbytes} bytes during a HIP-graph capture: run the "
+                                         "step once eagerly at this shape first")
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf
@@ -115,8 +130,8 @@ class NormPartials:
     (lg_*_dgrad_nf): `buf` holds [B][nparts][2] doubles.  Valid until the next fused data gradient is enqueued (one
     shared workspace; kernels of a stream run in order and the consumer is the very next norm backward)."""
 
-    def __init__(self, buf, nparts):
-        self.buf, self.nparts = buf, nparts
+    def __init__(self, buf, nparts, alpha, shape):
+        self.buf, self.nparts, self.alpha, self.shape = buf, nparts, float(alpha), tuple(shape)
 
 
 def _nf_args(fuse, B, up, Hs, Ws, N, device):
@@ -148,7 +163,7 @@ def conv2d_s2_dgrad(dy, pack, cb, dtype, out=None, dy16=None, out_bf16=False, fu
         check(_lib.load().lg_conv2d_s2_dgrad_nf(_p(dy16), _p(pack), _p(out), B, Hs, Ws, cb, cs, _p(z16), _p(st), alpha, _p(ws),
                                                ws.numel(), ctypes.addressof(npo), _stream()), "lg_conv2d_s2_dgrad_nf")
         _pe(e0, "conv_igemm_up", 50.0 * B * Hs * Ws * cb * cs)
-        return out, (NormPartials(ws, npo.value) if npo.value > 0 else None)
+        return out, (NormPartials(ws, npo.value, alpha, out.shape) if npo.value > 0 else None)
     if dy is not None:
         _chk(dy, name="dy")
     if dy16 is not None:
@@ -233,7 +248,7 @@ def convT_s2_dgrad(dy, pack, cs, dtype, out=None, dy16=None, out_bf16=False, fus
         check(_lib.load().lg_convT_s2_dgrad_nf(_p(dy16), _p(pack), _p(out), B, H // 2, W // 2, cb, cs, _p(z16), _p(st), alpha,
                                               _p(ws), ws.numel(), ctypes.addressof(npo), _stream()), "lg_convT_s2_dgrad_nf")
         _pe(e0, "conv_igemm_down", 50.0 * B * (H // 2) * (W // 2) * cb * cs)
-        return out, (NormPartials(ws, npo.value) if npo.value > 0 else None)
+        return out, (NormPartials(ws, npo.value, alpha, out.shape) if npo.value > 0 else None)
     if dy is not None:
         _chk(dy, name="dy")
     if dy16 is not None:
@@ -335,7 +350,7 @@ def convT_s1_tanh_bwd(x, dpre, pack, cs, dtype, dx=None, dw=None, db=None, accum
         check(lib.lg_convT_s1_tanh_bwd_nf(_p(x), _p(x16), _p(dpre), _p(pack), _p(dx16), _p(dw), _p(db), _p(ws), ws.numel(), B, H, W,
                                           cb, cs, int(accumulate), dtype, _p(z16), _p(st), alpha, _p(wsp), wsp.numel(),
                                           ctypes.addressof(npo), _stream()), "lg_convT_s1_tanh_bwd_nf")
-        return dx16, (NormPartials(wsp, npo.value) if npo.value > 0 else None)
+        return dx16, (NormPartials(wsp, npo.value, alpha, dx16.shape) if npo.value > 0 else None)
     check(lib.lg_convT_s1_tanh_bwd_m16(_p(x), _p(x16), _p(dpre), _p(pack), _p(dx), _p(dx16), _p(dw), _p(db), _p(ws),
                                        ws.numel(), B, H, W, cb, cs, int(accumulate), dtype, _stream()),
           "lg_convT_s1_tanh_bwd_m16")
@@ -479,6 +494,10 @@ def instnorm_bwd(x, stats, g, dgamma, dbeta, pre_leaky, post_leaky, alpha, accum
     if partials is not None:  # NormPartials from the conv that produced g: the first pass over (x, g) is skipped
         if not x_is16:
             raise ValueError("instnorm_bwd: fused partial sums belong to the bf16 activation path")
+        # the producer's store loop hard-codes g' = LeakyReLU'_alpha(a c + b) g (lg_nf_accum): anything else is another sum
+        if pre_leaky or not post_leaky or float(alpha) != partials.alpha or tuple(x.shape) != partials.shape:
+            raise ValueError(f"instnorm_bwd: partial sums were produced for the post-LeakyReLU(alpha={partials.alpha}) form on "
+                             f"shape {partials.shape}; asked for pre={pre_leaky} post={post_leaky} alpha={alpha} shape {tuple(x.shape)}")
         check(lib.lg_instnorm_leaky_bwd_z16_p(_p(x), _p(stats), _p(g), int(g16), _p(out), _p(out16), _p(dgamma), _p(dbeta), _p(db), C,
                                               _p(partials.buf), int(partials.nparts), _p(ws), ws.numel(), B, Ln, int(pre_leaky),
                                               int(post_leaky), float(alpha), int(accumulate), _stream()),

@@ -78,7 +78,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_q):
+def _worker(rank, world, port, out_q, batch_no=11):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -89,7 +89,7 @@ def _worker(rank, world, port, out_q):
         Bg = cfg.batch_size * world
         full = O.make_inputs(cfg, Bg, seed=77)
         shard = {k: torch.tensor(v[rank * cfg.batch_size:(rank + 1) * cfg.batch_size]) for k, v in full.items()}
-        out = T.step_gradients(T.Net(cfg, W, torch.float64), 11, shard)
+        out = T.step_gradients(T.Net(cfg, W, torch.float64), 11, shard)   # full gradient sets; the exchange below picks ranges
         store, g, d, adj = _store(cfg)
         store.grad = store.grad.double()
         for m, key in (("G", "dG"), ("D", "dD"), ("A", "dA")):
@@ -97,22 +97,25 @@ def _worker(rank, world, port, out_q):
                 store.grad[s:s + t.numel()] = t.reshape(-1)
         sync = GradSync("cpu")
         assert sync.enabled and sync.world_size == world
-        for m in ("D", "G", "A"):  # launch order of the step: D, G, A
-            sync.launch(m, store, *store.model_range(m))
+        from littlegan_amd.eager_trainer import train_weight_range
+        a = _args(cfg)
+        for m in ("D", "G", "A"):  # launch order of the step: D, G, A; a partition step exchanges its trained range only
+            sync.launch(m, store, *store.model_range(m, *train_weight_range(a, m, batch_no)))
         sync.wait_all()
-        store.grad /= world
         if rank == 0:
             out_q.put(store.grad.numpy().copy())
     finally:
         dist.destroy_process_group()
 
 
-def test_gradsync_two_ranks_equals_global_batch():
-    world = 2
+@pytest.mark.parametrize("world,batch_no", [(2, 11), (4, 11), (4, 15), (4, 20)])
+def test_gradsync_ranks_equal_global_batch(world, batch_no):
+    """world 2 / 4; batch_no 11 = a full step (three whole-model all-reduces), 15 / 20 = partition steps (group 0 / group 1 of G
+    and D: a range-limited all-reduce; the Adjuster has one group = always its whole range, eager_trainer.py:48-52,104-113)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, batch_no)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=300)
@@ -125,19 +128,29 @@ def test_gradsync_two_ranks_equals_global_batch():
     full = {k: torch.tensor(v) for k, v in O.make_inputs(cfg, cfg.batch_size * world, seed=77).items()}
     # the Adjuster branch concatenates along the batch, so the global-batch step must pair samples like the shards do:
     # evaluate the reference rank by rank on the SAME shards and average (losses are batch means of equal-size shards).
-    ref = None
+    ref, rank0 = None, None
     for r in range(world):
         shard = {k: v[r * cfg.batch_size:(r + 1) * cfg.batch_size] for k, v in full.items()}
         o = T.step_gradients(T.Net(cfg, W, torch.float64), 11, shard)
         flat = {m: [t.reshape(-1).numpy() for t in o[k]] for m, k in (("G", "dG"), ("D", "dD"), ("A", "dA"))}
+        rank0 = flat if rank0 is None else rank0
         ref = flat if ref is None else {m: [a + b for a, b in zip(ref[m], flat[m])] for m in ref}
     # and, for the G/D tapes (no batch concatenation), directly against ONE process on the concatenated global batch
     og = T.step_gradients(T.Net(cfg_g, W, torch.float64), 5, full)
     store, *_ = _store(cfg)
+    from littlegan_amd.eager_trainer import train_weight_range
+    a = _args(cfg)
+    trained = {m: range(*train_weight_range(a, m, batch_no)) for m in "GDA"}
+    assert (len(trained["G"]), len(trained["D"])) == {11: (22, 20), 15: (4, 12), 20: (4, 4)}[batch_no] and len(trained["A"]) == 4
     for m in "GDA":
         for i, ((s, e), t) in enumerate(zip(store.ranges[m], ref[m])):
-            assert np.allclose(got[s:s + t.size], t / world, rtol=1e-9, atol=1e-13)
+            if i in trained[m]:   # exchanged: sum over ranks (the 1 / world scale sits in the Adam kernel, dist.py)
+                assert np.allclose(got[s:s + t.size], t, rtol=1e-9, atol=1e-13), (m, i)
+            else:                 # outside the partition group: untouched by the exchange
+                assert np.allclose(got[s:s + t.size], rank0[m][i], rtol=1e-9, atol=1e-13), (m, i)   # (== rank 0's own gradient)
+                assert not np.allclose(got[s:s + t.size], t, rtol=1e-3, atol=0) or np.abs(t).max() == 0, (m, i)
     for m, key in (("G", "dG"), ("D", "dD")):
-        for (s, e), t in zip(store.ranges[m], og[key]):
+        for i, ((s, e), t) in enumerate(zip(store.ranges[m], og[key])):
             t = t.reshape(-1).numpy()
-            assert np.allclose(got[s:s + t.size], t, rtol=1e-9, atol=1e-13), (m, np.abs(got[s:s + t.size] - t).max())
+            if i in trained[m]:
+                assert np.allclose(got[s:s + t.size] / world, t, rtol=1e-9, atol=1e-13), (m, np.abs(got[s:s + t.size] / world - t).max())

@@ -21,7 +21,9 @@ ALPHA = 0.3
 LAYERS = [("enc.conv1", "conv", 3, 64, 64), ("enc.conv2", "conv", 64, 128, 32), ("enc.conv3", "conv", 128, 256, 16),
           ("enc.conv4", "conv", 256, 384, 8), ("dec.conv1", "convT", 256, 384, 8), ("dec.conv2", "convT", 128, 256, 16),
           ("dec.conv3", "convT", 64, 128, 32), ("dec.conv4", "convT", 32, 64, 64)]
-CONFIGS = [pytest.param(1, 256, id="bf16-B256"), pytest.param(0, 64, id="f32-B64")]
+# B = 512: the C3 step runs D on [new_image ; fake] and the whole Adjuster branch on [img1 ; fake] at 2 x 256 images
+# (littlegan_amd/eager_trainer.py: train_step_from_inputs; reference eager_trainer.py:134-137,152-163)
+CONFIGS = [pytest.param(1, 256, id="bf16-B256"), pytest.param(1, 512, id="bf16-B512"), pytest.param(0, 64, id="f32-B64")]
 CHUNK = 32
 
 
@@ -136,6 +138,8 @@ def test_data_gradient(ops, layer, dt, B):
 def test_weight_gradient_full_batch(ops, layer, dt, B):
     """split-K over the whole batch + ordered slab reduce, against the oracle on the FULL batch"""
     name, kind, cb, cs, s = layer
+    if B == 512 and kind == "convT":
+        pytest.skip("no tape of the step takes decoder weight gradients at 2B (the Adjuster trains its dense + norm only)")
     big = _rand((B, 2 * s, 2 * s, cb), 21)
     small = _rand((B, s, s, cs), 22, 0.1)
     b16 = big.to(torch.bfloat16) if (dt == 1 and cb != 3) else None
@@ -264,7 +268,8 @@ def test_final_layer(ops, dt, B):
 
 def test_whole_step_forward_rows_at_batch_256():
     """The bench configuration itself (C3: 128x128, B = 256, bf16, reference widths): generated images of sampled rows of
-    the batch against the bf16-emulating oracle (the forward is per-sample), and the losses of a full step are finite."""
+    the batch against the bf16-emulating oracle (the forward is per-sample), and D's head probabilities on those rows (forward only;
+    the full step at this batch is test_whole_step_at_launch_batch below)."""
     from test_step_gpu import build, dev_inputs, f32_round, perturbed
     cfg = O.Cfg(init_dim=8, cond_dim=40, batch_size=256)
     W = perturbed(cfg, 7)
@@ -282,3 +287,184 @@ def test_whole_step_forward_rows_at_batch_256():
     (pr, pc), _ = O.discriminator_fwd(cfg_e, W["D"], got)   # D on the kernel's own images (see tests/replay.py)
     gp = _f64(p[idx])
     assert np.abs(gp[:, :1] - pr).max() < 5e-3 and np.abs(gp[:, 1:] - pc).max() < 5e-3
+
+
+# ---- data gradients in the FUSED form the step launches (lg_*_dgrad_nf + lg_instnorm_leaky_bwd_z16_p) -----------------------
+# (name, kind of the layer whose data gradient runs, cb, cs, small side s, sums fused at these shapes)
+#   conv  : dy16 [B,s,s,cs]   -> g [B,2s,2s,cb] = gradient of the encoder level below; UP contraction (conv_up3 / conv_up4 / conv_halo)
+#   convT : dy16 [B,2s,2s,cb] -> g [B,s,s,cs]   = gradient of the decoder level below; DOWN contraction (conv_down3)
+FUSED = [("enc.conv2", "conv", 64, 128, 32, True), ("enc.conv3", "conv", 128, 256, 16, True), ("enc.conv4", "conv", 256, 384, 8, False),
+         ("dec.conv2", "convT", 128, 256, 16, True), ("dec.conv3", "convT", 64, 128, 32, True), ("dec.conv4", "convT", 32, 64, 64, True)]
+
+
+def _norm_ref(zs, gs, ss):
+    """oracle of the InstanceNorm + LeakyReLU backward on sampled images from the kernel's statistics records (LeakyReLU mask in
+    the kernels' fp32 order, as tests/replay.py does)"""
+    mu, sigma, a = (ss[:, 0] + ss[:, 4])[:, None], ss[:, 1][:, None], ss[:, 2][:, None]
+    c = zs - mu
+    s32 = ss.astype(np.float32)
+    y32 = (s32[:, 2:3] * ((zs.astype(np.float32) - s32[:, 0:1]) - s32[:, 4:5])).astype(np.float32) + s32[:, 3:4]
+    gp = np.where(y32 > 0, gs, ALPHA * gs)
+    return a * (gp - gp.mean(1, keepdims=True) - c * (gp * c).mean(1, keepdims=True) / ((sigma + 1e-3) * sigma))
+
+
+@pytest.mark.parametrize("B", [256, 512])
+@pytest.mark.parametrize("layer", FUSED, ids=[l[0] for l in FUSED])
+def test_fused_data_gradient_and_norm_backward(ops, layer, B):
+    """The bf16 step never calls the plain data gradient on these layers: it calls lg_conv2d_s2_dgrad_nf / lg_convT_s2_dgrad_nf
+    (the conv's store loop also adds up sum g', sum g'c of the norm backward below, [B][nparts][2] doubles in a workspace that
+    scales with the batch) and then lg_instnorm_leaky_bwd_z16_p.  At B = 256 (gen tape, rows of the fake half) and B = 512 (disc
+    tape, Adjuster branch): gradient and dz against the oracle on sampled images, the fused sums against the stand-alone
+    first pass, chunk equality, and WHICH shapes really fuse."""
+    name, kind, cb, cs, s, expect = layer
+    w = _rand((5, 5, cb, cs), 51, 0.05)
+    pack = ops.conv_pack(w, cb, cs, 1)
+    dy = _rand((B, s, s, cs) if kind == "conv" else (B, 2 * s, 2 * s, cb), 52)
+    dy16 = dy.to(torch.bfloat16)
+    gshape = (B, 2 * s, 2 * s, cb) if kind == "conv" else (B, s, s, cs)
+    z16 = _rand(gshape, 53, 1.7).add_(0.4).to(torch.bfloat16)      # raw conv output of the level the gradient belongs to
+    gm, bt = torch.tensor([0.9], device="cuda"), torch.tensor([0.15], device="cuda")
+    st = ops.instnorm_stats(z16.float(), gm, bt, 0, ALPHA)
+    dgrad = ops.conv2d_s2_dgrad if kind == "conv" else ops.convT_s2_dgrad
+    cout = cb if kind == "conv" else cs
+
+    def run(lo, hi, fuse):
+        r = dgrad(None, pack, cout, 1, dy16=dy16[lo:hi], out_bf16=True, fuse=(z16[lo:hi], st[lo:hi], ALPHA) if fuse else None)
+        return r if fuse else (r, None)
+
+    g, parts = run(0, B, True)
+    assert (parts is not None) == expect, (name, B, None if parts is None else parts.nparts)
+    idx = _samples(B)
+    dq, wq = O.bf16_round(_f64(dy16[idx])), O.bf16_round(_f64(w))
+    ref = O.conv_bwd_input(dq, wq, 2, (2 * s, 2 * s)) if kind == "conv" else O.conv_fwd(dq, wq, 2)
+    assert _rms(_f64(g[idx]), O.bf16_round(ref)) < 6e-4
+    # norm backward from the fused sums (must be consumed before the next fused launch reuses the workspace)
+    C = gshape[-1]
+    outs = []
+    for p in ((parts, None) if parts is not None else (None,)):
+        dgm, dbt, db = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda"), torch.zeros(C, device="cuda")
+        dz16 = torch.empty(gshape, dtype=torch.bfloat16, device="cuda")
+        ops.instnorm_bwd(z16, st, g, dgm, dbt, 0, 1, ALPHA, out16=dz16, want_f32=False, db=db, partials=p)
+        outs.append((dz16, float(dgm), float(dbt), db))
+    dref = _norm_ref(_f64(z16[idx]).reshape(len(idx), -1), _f64(g[idx]).reshape(len(idx), -1), _f64(st[idx]))
+    assert _rms(_f64(outs[0][0][idx]).reshape(len(idx), -1), O.bf16_round(dref)) < 6e-4
+    if parts is not None:
+        gabs = float(g.float().abs().sum())
+        assert _rms(_f64(outs[0][0]), _f64(outs[1][0])) < 2e-4          # (a few flipped bf16 roundings: sums differ in their last bits)
+        assert abs(outs[0][1] - outs[1][1]) <= 1e-6 * gabs and abs(outs[0][2] - outs[1][2]) <= 1e-6 * gabs
+        assert _rms(_f64(outs[0][3]), _f64(outs[1][3])) < 1e-5
+    # the unfused kernel writes the same gradient; 32-image chunks of the fused launch equal the big launch bit for bit
+    g_plain, _ = run(0, B, False)
+    assert _rms(_f64(g[idx]), _f64(g_plain[idx])) < 1e-6 or torch.equal(g, g_plain)
+    for lo in range(0, B, CHUNK):
+        gc, pc = run(lo, lo + CHUNK, True)
+        assert torch.equal(gc, g[lo:lo + CHUNK]), (name, lo)
+        assert (pc is not None) == expect
+
+
+@pytest.mark.parametrize("B", [256, 512])
+def test_final_layer_fused_data_gradient(ops, B):
+    """lg_convT_s1_tanh_bwd_nf as the gen tape (B = 256, with the weight gradient) and the Adjuster branch (B = 512, data
+    gradient only) launch it: bf16 dx + the norm-backward sums of decoder level 4."""
+    H, cs = 128, 32
+    w = _rand((5, 5, 3, cs), 61, 0.05)
+    pack = ops.conv_pack(w, 3, cs, 1)
+    dpre = _rand((B, H, H, 3), 62, 0.01)
+    z16 = _rand((B, H, H, cs), 63, 1.7).add_(0.4).to(torch.bfloat16)
+    gm, bt = torch.tensor([0.9], device="cuda"), torch.tensor([0.15], device="cuda")
+    st = ops.instnorm_stats(z16.float(), gm, bt, 0, ALPHA)
+    x16 = _rand((B, H, H, cs), 64).to(torch.bfloat16)
+    wg = B == 256
+    dx = torch.empty((B, H, H, cs), dtype=torch.bfloat16, device="cuda")
+    dw, db = torch.empty(5, 5, 3, cs, device="cuda"), torch.empty(3, device="cuda")
+    _, parts = ops.convT_s1_tanh_bwd(None, dpre, pack, cs, 1, dx16=dx, dw=dw if wg else None, db=db if wg else None,
+                                     x16=x16 if wg else None, fuse=(z16, st, ALPHA))
+    assert parts is not None
+    idx = _samples(B)
+    dref = O.conv_fwd(O.bf16_round(_f64(dpre[idx])), O.bf16_round(_f64(w)), 1)
+    assert _rms(_f64(dx[idx]), O.bf16_round(dref)) < 6e-4
+    outs = []
+    for p in (parts, None):
+        dgm, dbt = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+        dz16 = torch.empty_like(z16)
+        ops.instnorm_bwd(z16, st, dx, dgm, dbt, 0, 1, ALPHA, out16=dz16, want_f32=False, partials=p)
+        outs.append((dz16, float(dgm), float(dbt)))
+    nref = _norm_ref(_f64(z16[idx]).reshape(len(idx), -1), _f64(dx[idx]).reshape(len(idx), -1), _f64(st[idx]))
+    assert _rms(_f64(outs[0][0][idx]).reshape(len(idx), -1), O.bf16_round(nref)) < 6e-4
+    gabs = float(dx.float().abs().sum())
+    assert _rms(_f64(outs[0][0]), _f64(outs[1][0])) < 2e-4
+    assert abs(outs[0][1] - outs[1][1]) <= 1e-6 * gabs and abs(outs[0][2] - outs[1][2]) <= 1e-6 * gabs
+    if wg:
+        ref_w = O.conv_bwd_filter(O.bf16_round(_f64(dpre)), O.bf16_round(_f64(x16)), 1, 5)
+        assert _rms(_f64(dw), ref_w) < 3e-5
+    for lo in range(0, B, CHUNK):
+        dc = torch.empty((CHUNK, H, H, cs), dtype=torch.bfloat16, device="cuda")
+        ops.convT_s1_tanh_bwd(None, dpre[lo:lo + CHUNK], pack, cs, 1, dx16=dc, fuse=(z16[lo:lo + CHUNK], st[lo:lo + CHUNK], ALPHA))
+        assert torch.equal(dc, dx[lo:lo + CHUNK]), lo
+
+
+@pytest.mark.parametrize("init_dim,B,chunk", [pytest.param(8, 256, 32, id="C3-128px-B256"), pytest.param(16, 64, 16, id="C5geom-256px-B64")])
+def test_whole_step_at_launch_batch(init_dim, B, chunk):
+    """ONE WHOLE bf16 step (b = 11: G, D on 2B, disc tape, gen tape, Adjuster branch on 2B, three Adam applies) at the batch
+    bench.py times (C3: 128x128, B = 256) and at the C5 geometry (256x256; B = 64 keeps the run short):
+      * fake / adjusted images and D's head probabilities of sampled rows against the bf16-emulating oracle (per-sample ops);
+      * the three loss scalars and EVERY gradient tensor against the same step run on `chunk`-image slices of the batch with
+        the same weights (losses are batch means, so the big step must equal the mean over the slices): this is the check that
+        no launch of the big step (2B = 512 grids, batch-scaled workspaces, split-K factors) mixes or drops samples.
+    Reference: eager_trainer.py:133-168."""
+    from test_step_gpu import build, dev_inputs, f32_round, perturbed
+    cfg = O.Cfg(init_dim=init_dim, cond_dim=40, batch_size=B)
+    W = perturbed(cfg, 7)
+    tr = build(cfg, W, "bf16")
+    inp = f32_round(O.make_inputs(cfg, B, seed=21))
+    d_in = dev_inputs(inp)
+    fake, adj, lg, ld, la = tr.train_step_from_inputs(11, d_in)
+    torch.cuda.synchronize()
+    grads = tr.store.grad.clone()
+    losses = np.array([lg.item(), ld.item(), la.item()])
+    assert np.isfinite(losses).all() and torch.isfinite(grads).all()
+    # ---- sampled rows against the emulating oracle
+    idx = _samples(B)
+    cfg_e = O.Cfg(init_dim=init_dim, cond_dim=40, batch_size=len(idx), emulate_bf16=True)
+    ref, _ = O.generator_fwd(cfg_e, W["G"], inp["noise"][idx], inp["real_cond_2"][idx])
+    got = _f64(fake[idx])
+    assert np.abs(got - ref).max() < 2e-2 and _rms(got, ref) < 3e-3
+    # Adjuster rows: sample i of the first half is img1[i] with cond (c2[i]+1)/2, of the second half fake[i] with (c1[i]+1)/2
+    a_img = np.concatenate([inp["real_image_1"][idx], got], 0)
+    a_cond = (np.concatenate([inp["real_cond_2"][idx], inp["real_cond_1"][idx]], 0) + 1.0) * 0.5
+    cfg_a = O.Cfg(init_dim=init_dim, cond_dim=40, batch_size=2 * len(idx), emulate_bf16=True)
+    a_ref, _ = O.adjuster_fwd(cfg_a, W, a_img, a_cond)
+    a_got = np.concatenate([_f64(adj[idx]), _f64(adj[[B + i for i in idx]])], 0)
+    assert np.abs(a_got - a_ref).max() < 4e-2 and _rms(a_got, a_ref) < 6e-3
+    # ---- the same step on slices of the batch, same weights (lr = 0: the applies leave them alone)
+    cfg_c = O.Cfg(init_dim=init_dim, cond_dim=40, batch_size=chunk)
+    trc = build(cfg_c, W, "bf16")
+    trc.opt_cfg = {m: (0.0, b1, b2) for m, (_, b1, b2) in trc.opt_cfg.items()}
+    acc = torch.zeros_like(grads, dtype=torch.float64)
+    lacc = np.zeros(3)
+    n = B // chunk
+    for k in range(n):
+        sl = {key: v[k * chunk:(k + 1) * chunk].contiguous() for key, v in d_in.items()}
+        fk, ak, lgk, ldk, lak = trc.train_step_from_inputs(11, sl)
+        assert float((fk - fake[k * chunk:(k + 1) * chunk]).abs().max()) < 2e-2, ("fake rows differ from the slice run", k)
+        acc += trc.store.grad.double()
+        lacc += np.array([lgk.item(), ldk.item(), lak.item()])
+    assert np.abs(lacc / n - losses).max() < 2e-5 * np.abs(losses).max(), (lacc / n, losses)
+    mean = (acc / n)
+    worst = []
+    for m in "DGA":
+        for i, (s, e) in enumerate(tr.store.ranges[m]):
+            a, b = grads[s:e].double(), mean[s:e]
+            den = float(b.pow(2).mean().sqrt()) + 1e-30
+            worst.append((float((a - b).pow(2).mean().sqrt()) / den, m, i))
+    worst.sort(reverse=True)
+    print("whole step vs slices: worst gradient tensors", worst[:5])
+    # tensors of 1 element (gamma / beta) are sums with heavy cancellation: bound them against the largest gradient instead
+    gmax = float(grads.abs().max())
+    numel = {m: [t[5] for t in tr.store.index if t[0] == m] for m in "DGA"}
+    for r, m, i in worst:
+        s, e = tr.store.ranges[m][i]
+        if numel[m][i] == 1:
+            assert abs(float(grads[s]) - float(mean[s])) <= 2e-3 * gmax, (m, i)
+        else:
+            assert r < 2e-3, (m, i, r)

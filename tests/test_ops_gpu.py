@@ -148,7 +148,8 @@ def test_instnorm_constant_sample_is_beta(ops):
     assert torch.allclose(y, torch.full_like(y, -0.4), atol=1e-6)
 
 
-@pytest.mark.parametrize("B,K,N", [(5, 133, 24576), (3, 16, 256), (17, 40, 1024), (64, 133, 24576), (32, 16, 256), (96, 37, 1024)])  # the last three: fp32-MFMA kernels (skinny_mfma.hip)
+@pytest.mark.parametrize("B,K,N", [(5, 133, 24576), (3, 16, 256), (17, 40, 1024), (64, 133, 24576), (32, 16, 256), (96, 37, 1024),
+                                   (256, 133, 24576), (512, 40, 24576)])  # from (64, ...) on: fp32-MFMA kernels (skinny_mfma.hip); the last two: G.dense at B = 256, A.dense at 2B = 512 (the C3 launch shapes)
 def test_dense_fwd_wgrad(ops, B, K, N):
     rng = np.random.default_rng(3)
     x, w, b, dy = r32(rng, B, K), r32(rng, K, N, scale=0.1), r32(rng, N), r32(rng, B, N)
@@ -159,7 +160,8 @@ def test_dense_fwd_wgrad(ops, B, K, N):
     assert rel(dw, x.T @ dy) < 1e-5 and rel(db, dy.sum(0)) < 1e-5
 
 
-@pytest.mark.parametrize("B,K,c", [(5, 24576, 40), (4, 256, 5), (3, 1024, 7), (64, 24576, 40), (64, 1024, 5), (128, 512, 33)])  # the last three: fp32-MFMA kernels
+@pytest.mark.parametrize("B,K,c", [(5, 24576, 40), (4, 256, 5), (3, 1024, 7), (64, 24576, 40), (64, 1024, 5), (128, 512, 33),
+                                   (256, 24576, 40), (512, 24576, 40)])  # from (64, ...) on: fp32-MFMA kernels; the last two: the C3 launch shapes (gen tape B = 256; D forward / disc tape / Adjuster branch 2B = 512)
 def test_heads_fwd_dgrad_wgrad(ops, B, K, c):
     rng = np.random.default_rng(4)
     x = r32(rng, B, K)

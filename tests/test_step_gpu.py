@@ -256,6 +256,43 @@ def test_graph_replay_is_bit_exact():
     assert len(tr_g._graphs) == 5   # (-1, False), (-1, True) and the three partition groups with the Adjuster on
 
 
+def test_graph_replay_survives_workspace_growth():
+    """A captured graph holds the raw addresses of ops.workspace() scratch buffers.  When a later, larger call outgrows one
+    of them the old buffer must stay allocated (retired), not go back to the caching allocator where a new tensor could land
+    under the replaying graph's writes; and capturing must leave ops.Profile.enabled as it found it."""
+    from littlegan_amd import ops
+    cfg = O.Cfg(init_dim=2, conv_filter=(64, 32, 32, 64, 32), cond_dim=5, noise_dim=11, batch_size=3)
+    W = perturbed(cfg, 5)
+    tr_e, tr_g = build(cfg, W, "bf16"), build(cfg, W, "bf16")
+    ops.Profile.enabled = True
+    try:
+        inps = {b: dev_inputs(f32_round(O.make_inputs(cfg, cfg.batch_size, seed=400 + b))) for b in (11, 12, 13, 14)}
+        for b in (11, 12):   # eager, then captured
+            tr_e.train_step_from_inputs(b, inps[b])
+            tr_g.graph_step(b, inps[b])
+        assert ops.Profile.enabled, "graph capture must restore Profile.enabled"
+    finally:
+        ops.Profile.stop()
+    assert len(tr_g._graphs) == 1
+    before = {k: v.data_ptr() for k, v in ops._WS.items()}
+    n_ret = len(ops._WS_RETIRED)
+    # outgrow every scratch tag the step uses (as a later predict / FID / bigger Adjuster step would)
+    for (dev_, tag), ptr in before.items():
+        ops.workspace(ops._WS[(dev_, tag)].numel() * 2, torch.device(dev_), tag)
+    grown = [k for k, v in ops._WS.items() if k in before and v.data_ptr() != before[k]]
+    assert grown, "no workspace grew: the test lost its subject"
+    assert len(ops._WS_RETIRED) >= n_ret + len(grown)
+    assert {b.data_ptr() for b in ops._WS_RETIRED} >= {before[k] for k in grown}   # the captured addresses are still owned
+    junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]   # would land in a freed buffer
+    for b in (13, 14):   # replays of the graph captured BEFORE the growth
+        fe, ae, lge, lde, lae = tr_e.train_step_from_inputs(b, inps[b])
+        fg, ag, lgg, ldg, lag = tr_g.graph_step(b, inps[b])
+        torch.cuda.synchronize()
+        assert torch.equal(fe, fg) and torch.equal(ae, ag) and torch.equal(lge, lgg) and torch.equal(lde, ldg)
+        assert torch.equal(tr_e.store.flat, tr_g.store.flat)
+    assert all(bool(torch.isnan(j).all()) for j in junk)
+
+
 def test_checkpoint_resume_is_bit_exact(tmp_path):
     """Own-format checkpoint with the reference's CONTENT (eager_trainer.py:31-43: the three models, the three
     optimizers' slots and beta powers, status.json epoch): train 3 steps, save, train a 4th; a fresh trainer that
