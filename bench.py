@@ -179,9 +179,12 @@ def main():
     barrier()
     if not a.graph:
         ops.Profile.start()
+    tr.sync.time_waits = world > 1
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(b0 + a.warmup + i, inp)
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0   # this rank's own time for its K steps (before the closing barrier)
     barrier()
     dt = time.perf_counter() - t0
     if a.graph:  # per-launch HIP events cannot sit inside a replayed graph: the roofline leg times 5 eager steps afterwards
@@ -205,30 +208,51 @@ def main():
             tr.graph_step(bg + 30 + i, inp)
         torch.cuda.synchronize()
         graph_ms = (time.perf_counter() - tg) / 30 * 1e3
+    dp_info = None
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # per-rank view beside the MAX-reduced figure: each rank's own ms/step and how long its compute stream stalled in
+        # GradSync.wait_all() (event pair on the compute stream; 0 = the three all-reduces were hidden under the backward)
+        wait_ms = sum(e0.elapsed_time(e1) for e0, e1 in tr.sync.wait_events) / max(a.steps, 1)
+        mine = torch.tensor([dt_own / a.steps * 1e3, wait_ms], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        own = [float(x[0]) for x in allr]
+        waits = [float(x[1]) for x in allr]
+        dp_info = {"per_rank_ms_per_step": {"min": round(min(own), 3), "max": round(max(own), 3)},
+                   "allreduce_wait_ms_per_step": {"min": round(min(waits), 3), "max": round(max(waits), 3)},
+                   "backend": a.backend, "launch": "eager (graph_step falls back to eager launches under data parallelism)",
+                   "allreduce_payload_mb": {m: round((tr.store.model_range(m)[1] - tr.store.model_range(m)[0]) * 4 / 1e6, 2) for m in "DGA"}}
 
     if rank == 0:
         ms = dt / a.steps * 1e3
         gb = args.batch_size * world
         value = gb / (dt / a.steps)
         dt_name = args.mfma_dtype
-        # dominant kernel = the conv contraction class with the largest measured time
-        tag, (n, fl, sec) = max(prof.items(), key=lambda kv: kv[1][2])
+        # ops.Profile keys are "<contraction class>:<kernel template the C side launched>" (lg_last_kernel)
+        by_kernel, by_class = {}, {}
+        for key, (n_, fl_, sec_) in prof.items():
+            cls, _, kern = key.partition(":")
+            for d, k in ((by_kernel, kern or cls), (by_class, cls)):
+                r = d.setdefault(k, [0, 0.0, 0.0])
+                r[0] += n_; r[1] += fl_; r[2] += sec_
+        # dominant kernel = the kernel template with the largest measured time in the timed region
+        tag, (n, fl, sec) = max(by_kernel.items(), key=lambda kv: kv[1][2])
         ach = fl / sec / 1e12
-        # HBM-side bytes per launch of that kernel class: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) cannot run inside
-        # this process; they are collected on this same command and committed (scripts/pmc_traffic.py)
+        # HBM-side bytes per launch of that kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) cannot run inside this process;
+        # they are collected on this same command and committed (scripts/collect_profiles.sh -> scripts/pmc_traffic.py)
         traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_pmc_traffic.json")
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_pmc_traffic.json")
         if a.workload == "c3" and world == 1 and os.path.exists(tpath):
             rec = json.load(open(tpath)).get(tag)
             if rec:
-                traffic, traffic_src = rec["bytes_per_launch"], "profiles/r2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, offline)"
+                traffic, traffic_src = rec["bytes_per_launch"], "profiles/r3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, offline; goes stale when the kernel changes)"
         conv_sec = sum(v[2] for v in prof.values())
         conv_fl = sum(v[1] for v in prof.values())
+        nsteps_prof = 5 if a.graph else a.steps
         out = {
             "metric": {"c3": "128x128 CelebA-shaped images/sec (G+D+Adj step)", "c2": "128x128 CelebA-shaped images/sec (G+D step)",
                        "c5": "256x256 CelebA-shaped images/sec (G+D+Adj step)"}[a.workload],
@@ -245,13 +269,17 @@ def main():
                          "frac": round(ach / PEAK[dt_name], 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
                          "launches": n, "avg_launch_ms": round(sec / n * 1e3, 4),
+                         "all_kernels": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 2), "frac": round(v[1] / v[2] / 1e12 / PEAK[dt_name], 4),
+                                             "avg_launch_ms": round(v[2] / v[0] * 1e3, 4), "ms_per_step": round(v[2] / nsteps_prof * 1e3, 3)}
+                                         for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][2])},
                          "all_conv_kernels": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 2),
-                                                  "ms_per_step": round(v[2] / (5 if a.graph else a.steps) * 1e3, 3)} for k, v in prof.items()},
+                                                  "ms_per_step": round(v[2] / nsteps_prof * 1e3, 3)} for k, v in by_class.items()},
                          "conv_share_of_step": round(conv_sec / dt, 3),
                          "conv_tflops_overall": round(conv_fl / conv_sec / 1e12, 2),
                          "step_algorithmic_tflops": round(GFLOP_PER_IMAGE[a.workload] * args.batch_size / ms, 2)},
             "graph_replay": None if graph_ms is None else {"ms_per_step": round(graph_ms, 3), "value": round(args.batch_size / graph_ms * 1e3, 2),
                                                                "note": "same steps, one captured hipGraph per step kind, 30 timed steps after the headline region"},
+            "data_parallel": dp_info,
             "losses_last_step": losses,
             "parity": "checked against the in-repo fp64 restatement (tests/); parity to TensorFlow 1.15 is UNPINNED",
         }

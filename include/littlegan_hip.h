@@ -11,7 +11,11 @@
  *     state besides the thread-local error string;
  *   - `dtype` selects the MFMA operand type of the contraction: LG_DT_F32 = exact f32
  *     (v_mfma_f32_32x32x2_f32), LG_DT_BF16 = bf16 operands / f32 accumulate (v_mfma_f32_32x32x16_bf16).
- *     Storage in HBM is fp32 either way.
+ *     Storage in HBM: weights, their gradients, statistics records, images and image gradients are fp32 in both modes.
+ *     Activation-sized tensors are fp32 with LG_DT_F32; with LG_DT_BF16 the entry points that take `*16` pointers
+ *     (x16 / dy16 / z16 / out16 ...: bf16 tensors of the same shape) read and write them as bf16 ONLY — raw conv outputs,
+ *     activated maps and inter-layer gradients then never exist in fp32 (the "bf16 activation path").
+ *   - the thread-local strings of lg_last_error / lg_last_kernel are the only global state;
  * Stride-2 layers are described by (cb, cs, Hs, Ws): cb = channels of the BIG (2Hs x 2Ws) tensor,
  * cs = channels of the SMALL (Hs x Ws) tensor.  tf Conv2D kernels (HWIO, in=cb, out=cs) and
  * Conv2DTranspose kernels (HWOI, out=cb, in=cs) then share ONE memory layout [5][5][cb][cs].
@@ -34,6 +38,9 @@ extern "C" {
 
 int lg_abi_version(void);
 const char* lg_last_error(void);
+/* Name of the kernel template the calling thread's last conv / weight-gradient entry point launched ("" if none yet): a
+ * static string such as "conv_up3_kernel<64,32>".  Measurement aid (bench.py's per-kernel roofline); no reference counterpart. */
+const char* lg_last_kernel(void);
 
 /* ---- weight packing (once per layer per step; weights change every step) ------------------------
  * master kernel w[5][5][cb][cs] -> MFMA B-operand images in `dtype` (down pack + up pack). */

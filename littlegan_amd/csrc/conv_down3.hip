@@ -510,6 +510,7 @@ extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const 
   else if (stats) hipLaunchKernelGGL(conv_down3_kernel<true>, dim3(grid), dim3(256), LDS0, st, p);
   else hipLaunchKernelGGL(conv_down3_kernel<false>, dim3(grid), dim3(256), LDS0, st, p);
   LG_CHECK_LAUNCH("lg_conv_down3");
+  lg_note_kernel(pair ? "conv_down3_kernel<PAIR>" : n64 ? "conv_down3_kernel<NW=64>" : "conv_down3_kernel<NW=128>");
   if (stats || fuse) *nparts_out = p.nparts;
   return LG_OK;
 }

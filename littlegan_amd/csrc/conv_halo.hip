@@ -626,6 +626,9 @@ int launch(HaloParams p, hipStream_t st) {
   }
   if (p.dry) return LG_OK;
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  lg_note_kernel(MODE == MODE_DOWN ? (sizeof(T) == 2 ? "conv_halo_kernel<bf16,DOWN>" : "conv_halo_kernel<f32,DOWN>")
+                 : MODE == MODE_UP ? (RES ? "conv_halo_kernel<UP,resident>" : (sizeof(T) == 2 ? "conv_halo_kernel<bf16,UP,K-sliced>" : "conv_halo_kernel<f32,UP,K-sliced>"))
+                 : "conv_halo_kernel<S1T>");
   return LG_OK;
 }
 

@@ -304,6 +304,7 @@ int launch(const ConvParams& p, hipStream_t st) {
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, q);
+  lg_note_kernel(MODE == MODE_PATCH ? "conv_igemm_kernel<PATCH>" : MODE == MODE_UP ? "conv_igemm_kernel<UP>" : MODE == MODE_DOWN ? "conv_igemm_kernel<DOWN>" : "conv_igemm_kernel<S1T>");
   return LG_OK;
 }
 

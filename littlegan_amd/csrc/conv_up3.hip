@@ -451,6 +451,7 @@ extern "C" int lg_conv_up3_nf_try(const void* src16, const void* wpack_up, const
   if (Cs == 128) launch_up3<128, 64>(p, stats, st, fuse);
   else launch_up3<64, 32>(p, stats, st, fuse);
   LG_CHECK_LAUNCH("lg_conv_up3");
+  lg_note_kernel(Cs == 128 ? "conv_up3_kernel<128,64>" : "conv_up3_kernel<64,32>");
   if (stats || fuse) *nparts_out = p.tpi;
   return LG_OK;
 }

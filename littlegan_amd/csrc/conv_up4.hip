@@ -364,6 +364,7 @@ extern "C" int lg_conv_up4_nf_try(const void* src16, const void* wpack_up, const
   else if (stats) hipLaunchKernelGGL((conv_up4_kernel<true, false>), dim3(grid), dim3(256), LDS_BYTES, st, p);
   else hipLaunchKernelGGL((conv_up4_kernel<false, false>), dim3(grid), dim3(256), LDS_BYTES, st, p);
   LG_CHECK_LAUNCH("lg_conv_up4");
+  lg_note_kernel("conv_up4_kernel");
   if (stats || fuse) *nparts_out = p.nparts;
   return LG_OK;
 }

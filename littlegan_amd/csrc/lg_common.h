@@ -21,6 +21,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define LG_DT_BF16 1
 
 extern "C" void lg_set_error(const char* fmt, ...);
+// Names the kernel template a conv / weight-gradient entry point has just launched (thread-local, static strings only):
+// bench.py reads it back through lg_last_kernel() so that its roofline line names a KERNEL, not a class of kernels.
+extern "C" void lg_note_kernel(const char* name);
 
 #define LG_CHECK_ARG(cond, ...)            \
   do {                                     \

@@ -449,6 +449,7 @@ extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void
     else hipLaunchKernelGGL((n3_wgrad_kernel<2, false>), dim3(nblk), dim3(256), lds, st, big3, small, s16, slab, B, H, W, s, pad);
   }
   LG_CHECK_LAUNCH("lg_n3_wgrad");
+  lg_note_kernel((s16 && !getenv("LG_N3W_F32")) ? (Cs == 32 ? "n3_wgrad16_kernel<1>" : "n3_wgrad16_kernel<2>") : "n3_wgrad_kernel<f32>");
   const int n = 75 * Cs;
   hipLaunchKernelGGL(n3_slab_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, st, (const float*)workspace, dw, nblk, n,
                      accumulate);

@@ -366,6 +366,7 @@ extern "C" int lg_n3_s1t_fwd_p16_try(const void* x16, const float* w, const floa
   if (C == 32) hipLaunchKernelGGL(s1t_fwd_p16_kernel<32>, grid, dim3(256), 0, st, (const __bf16*)x16, w, bias, y, B, H, W);
   else hipLaunchKernelGGL(s1t_fwd_p16_kernel<64>, grid, dim3(256), 0, st, (const __bf16*)x16, w, bias, y, B, H, W);
   LG_CHECK_LAUNCH("lg_n3_s1t_fwd_p16");
+  lg_note_kernel("s1t_fwd_p16_kernel");
   return LG_OK;
 }
 
@@ -376,6 +377,7 @@ extern "C" int lg_n3_up_p16_try(const void* src16, const float* w, float* out, i
   if (C == 32) hipLaunchKernelGGL(up_p16_kernel<32>, grid, dim3(256), 0, st, (const __bf16*)src16, w, out, B, H, W);
   else hipLaunchKernelGGL(up_p16_kernel<64>, grid, dim3(256), 0, st, (const __bf16*)src16, w, out, B, H, W);
   LG_CHECK_LAUNCH("lg_n3_up_p16");
+  lg_note_kernel("up_p16_kernel");
   return LG_OK;
 }
 
@@ -396,6 +398,7 @@ extern "C" int lg_n3_conv1_fwd_p16_try(const float* img, const float* w, const f
   } else if (stats) hipLaunchKernelGGL((patch_p16_kernel<2, 64, false, true>), grid, dim3(256), 0, st, img, w, bias, z, nullptr, (double*)spart, B, H, W, 1);
   else hipLaunchKernelGGL((patch_p16_kernel<2, 64, false, false>), grid, dim3(256), 0, st, img, w, bias, z, nullptr, nullptr, B, H, W, 1);
   LG_CHECK_LAUNCH("lg_n3_conv1_fwd_p16");
+  lg_note_kernel("patch_p16_kernel<2,64>");
   if (stats) *nparts = tpi;
   return LG_OK;
 }
@@ -419,11 +422,13 @@ extern "C" int lg_n3_s1_dgrad_p16_nf_try(const float* dpre, const float* w, floa
   if (dx16 && nf && nf->z && nf->stats && nf->part && nparts_out && (size_t)B * tpi_ * 2 * sizeof(double) <= nf_bytes) {
     hipLaunchKernelGGL((patch_p16_kernel<1, 32, true, false, true>), grid, dim3(256), 0, st, dpre, w, nullptr, nullptr, (__bf16*)dx16, nullptr, B, H, W, 2, *nf);
     LG_CHECK_LAUNCH("lg_n3_s1_dgrad_p16(nf)");
+    lg_note_kernel("patch_p16_kernel<1,32,nf>");
     *nparts_out = tpi_;
     return LG_OK;
   }
   if (dx16) hipLaunchKernelGGL((patch_p16_kernel<1, 32, true, false>), grid, dim3(256), 0, st, dpre, w, nullptr, nullptr, (__bf16*)dx16, nullptr, B, H, W, 2);
   else hipLaunchKernelGGL((patch_p16_kernel<1, 32, false, false>), grid, dim3(256), 0, st, dpre, w, nullptr, dx, nullptr, nullptr, B, H, W, 2);
   LG_CHECK_LAUNCH("lg_n3_s1_dgrad_p16");
+  lg_note_kernel("patch_p16_kernel<1,32>");
   return LG_OK;
 }

@@ -206,5 +206,6 @@ extern "C" int lg_n3_s1t_fwd_rows_try(const void* x16, const float* stats, float
   if (stats) hipLaunchKernelGGL((s1t_fwd_rows_kernel<32, true>), grid, dim3(256), 0, st, x, w, bias, y, B, H, W, RB, ni);
   else hipLaunchKernelGGL((s1t_fwd_rows_kernel<32, false>), grid, dim3(256), 0, st, x, w, bias, y, B, H, W, RB, ni);
   LG_CHECK_LAUNCH("lg_n3_s1t_fwd_rows");
+  lg_note_kernel(stats ? "s1t_fwd_rows_kernel<32,NORM>" : "s1t_fwd_rows_kernel<32>");
   return LG_OK;
 }

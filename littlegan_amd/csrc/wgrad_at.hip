@@ -324,6 +324,7 @@ extern "C" int lg_wgrad_at_try(const void* big16, const void* small16, void* wor
   else if (sw == 16) hipLaunchKernelGGL((wgrad_at_kernel<16, 8>), dim3(p.nunits * ns), dim3(512), LDS16, st, p);
   else hipLaunchKernelGGL((wgrad_at_kernel<8, 8>), dim3(p.nunits * ns), dim3(512), LDS8, st, p);
   LG_CHECK_LAUNCH("lg_wgrad_at");
+  lg_note_kernel(sw == 32 ? "wgrad_at_kernel<32,4>" : sw == 16 ? "wgrad_at_kernel<16,8>" : "wgrad_at_kernel<8,8>");
   *nsplit_out = ns;
   return LG_OK;
 }

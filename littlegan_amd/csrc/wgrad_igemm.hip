@@ -356,6 +356,7 @@ void launch_wgrad(WgradParams p, int nsplit, hipStream_t st) {
   }
   dim3 grid(p.nti * p.ntj * p.ntaps * nsplit);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WI * WJ), lds, st, p);
+  lg_note_kernel(PATCH ? "wgrad_kernel<PATCH>" : BF16 ? "wgrad_kernel<bf16,per-tap>" : "wgrad_kernel<f32,per-tap>");
 }
 
 struct TileSel { int bi, bj; };

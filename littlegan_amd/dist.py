@@ -19,6 +19,8 @@ class GradSync:
         self.on_gpu = self.device.type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=self.device) if (self.enabled and self.on_gpu) else None
         self._pending = []
+        self.time_waits = False   # bench.py: record an event pair around every wait_all() on the compute stream
+        self.wait_events = []
 
     def launch(self, name, store, start, end):
         """All-reduce(sum) store.grad[start:end]; non-blocking for the compute stream."""
@@ -39,9 +41,17 @@ class GradSync:
 
     def wait_all(self):
         """Make the compute stream (or the host, on CPU) wait for every outstanding all-reduce."""
+        timed = self.time_waits and self.on_gpu and self.enabled and self._pending
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
         for p in self._pending:
             if self.on_gpu:
                 torch.cuda.current_stream(self.device).wait_event(p)
             else:
                 p.wait()
+        if timed:   # e1 - e0 = how long the compute stream sat waiting for gradients still on the wire (0 = fully overlapped)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream(self.device))
+            self.wait_events.append((e0, e1))
         self._pending.clear()

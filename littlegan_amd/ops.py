@@ -49,10 +49,12 @@ def _pb():
 
 
 def _pe(e0, tag, flops):
+    """tag = class of the contraction (what the FLOP formula depends on) + the kernel template the C side really launched"""
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        Profile.records.append((tag, float(flops), e0, e1))
+        kern = _lib.load().lg_last_kernel().decode()
+        Profile.records.append((f"{tag}:{kern}", float(flops), e0, e1))
 
 
 def _stream():

@@ -6,13 +6,11 @@ The csv carries GRBM_GUI_ACTIVE summed over the 8 XCDs, so max is taken as sum /
 The average shader clock during a kernel follows as (GUI_ACTIVE / 8) / duration."""
 import collections
 import csv
-import re
+import os
 import sys
 
-
-def short(n):
-    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
-    return re.sub(r"\(.*$", "", n)[:100]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import short  # noqa: E402  (the names bench.py's roofline.all_kernels uses)
 
 
 def main():

@@ -3,15 +3,18 @@ SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS 
 usage: python scripts/pmc_sq_waits.py counter_collection.csv [out.md]"""
 import collections
 import csv
-import re
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import short  # noqa: E402
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 dur = collections.defaultdict(float)
 seen = set()
 for r in rows:
-    n = re.sub(r"\(.*$", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""))[:100]
+    n = short(r["Kernel_Name"])
     agg[n][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Dispatch_Id"] not in seen:
         seen.add(r["Dispatch_Id"])

@@ -403,7 +403,7 @@ def test_final_layer_fused_data_gradient(ops, B):
         assert torch.equal(dc, dx[lo:lo + CHUNK]), lo
 
 
-@pytest.mark.parametrize("init_dim,B,chunk", [pytest.param(8, 256, 32, id="C3-128px-B256"), pytest.param(16, 64, 16, id="C5geom-256px-B64")])
+@pytest.mark.parametrize("init_dim,B,chunk", [pytest.param(8, 256, 32, id="C3-128px-B256"), pytest.param(16, 64, 32, id="C5geom-256px-B64")])
 def test_whole_step_at_launch_batch(init_dim, B, chunk):
     """ONE WHOLE bf16 step (b = 11: G, D on 2B, disc tape, gen tape, Adjuster branch on 2B, three Adam applies) at the batch
     bench.py times (C3: 128x128, B = 256) and at the C5 geometry (256x256; B = 64 keeps the run short):
