@@ -104,18 +104,22 @@ def load():
         raise LittleGanHipError(
             f"{LIB_PATH} not found: build it with `python -m littlegan_amd.csrc.build` "
             "(the LittleGAN hot path has no CPU fallback)")
-    # a library linked from objects built with ablation macros (LG_EXTRA_FLAGS of scripts/probe/*.sh: "results wrong, timing
-    # only") must never serve a test, a bench or a training run by accident
+    # Probe / ablation variants (scripts/probe/*: LG_EXTRA_FLAGS macros, "results wrong, timing only") live in their own
+    # liblittlegan_hip_<variant>.so and are loaded ONLY when LG_LIB_VARIANT names one; the product library must have been
+    # linked with the default flags.
     from .csrc import build as _build
-    fl = _build.built_flags()
-    if fl is not None and fl != " ".join(_build.FLAGS) and not os.environ.get("LG_ALLOW_PROBE_BUILD"):
-        raise LittleGanHipError(
-            f"{LIB_PATH} was built with non-default flags ({fl!r}): a probe / ablation build.  Rebuild with "
-            "`python -m littlegan_amd.csrc.build` (no LG_EXTRA_FLAGS), or set LG_ALLOW_PROBE_BUILD=1 for a timing probe")
+    variant = os.environ.get("LG_LIB_VARIANT") or None
+    path = _build.variant_paths(variant)[1]
+    if variant is None:
+        fl = _build.built_flags()
+        if fl is not None and fl != " ".join(_build.FLAGS):
+            raise LittleGanHipError(f"{LIB_PATH} was built with non-default flags ({fl!r}); rebuild with `python -m littlegan_amd.csrc.build`")
+    elif not os.path.exists(path):
+        raise LittleGanHipError(f"{path} not found: build it with LG_EXTRA_FLAGS=... python -m littlegan_amd.csrc.build --variant {variant}")
     # torch first: it ships its own libamdhip64 and must be the HIP runtime of the process.  If this library were loaded
     # before torch, the system runtime it links against would come in as a SECOND runtime and its kernels would see no device.
     import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res

@@ -18,9 +18,19 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def variant_paths(variant):
+    """A probe / ablation VARIANT (LG_EXTRA_FLAGS macros) is built beside the product library, never over it:
+    objects in csrc/build_<variant>/, library liblittlegan_hip_<variant>.so; loaded only when LG_LIB_VARIANT names it."""
+    if not variant:
+        return os.path.join(HERE, "build"), LIB
+    return os.path.join(HERE, "build_" + variant), os.path.join(PKG, f"liblittlegan_hip_{variant}.so")
+
+
+def build(force=False, verbose=True, variant=None):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
+    objdir, LIB = variant_paths(variant)
+    if not variant and os.environ.get("LG_EXTRA_FLAGS"):
+        raise SystemExit("LG_EXTRA_FLAGS needs --variant NAME: ablation builds never replace the product library")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(HERE, "lg_common.h"), os.path.join(os.path.dirname(PKG), "include", "littlegan_hip.h")]
 
@@ -29,9 +39,18 @@ def build(force=False, verbose=True):
     # can never be picked up silently by the next test / bench / training run.
     flags = FLAGS + os.environ.get("LG_EXTRA_FLAGS", "").split()
     flag_line = " ".join(flags)
+    # a variant may name the sources its macros touch (LG_VARIANT_SOURCES=conv_down3.hip,...): only those are compiled with the
+    # extra flags, every other object is the product build's (seconds instead of minutes per variant)
+    only = [s_ for s_ in os.environ.get("LG_VARIANT_SOURCES", "").split(",") if s_] if variant else []
+    base_objdir = os.path.join(HERE, "build")
 
     def cc(src):
         s = os.path.join(HERE, src)
+        if only and src not in only:
+            o = os.path.join(base_objdir, src.replace(".hip", ".o"))
+            if not os.path.exists(o):
+                raise SystemExit(f"{o} missing: build the product library first")
+            return o
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         fl = o + ".flags"
         same_flags = os.path.exists(fl) and open(fl).read() == flag_line
@@ -59,12 +78,12 @@ def build(force=False, verbose=True):
     return LIB
 
 
-def built_flags():
+def built_flags(variant=None):
     """The flag line the in-tree library was linked from (None if unknown) — _lib.load() refuses a probe build."""
-    p = os.path.join(HERE, "build", "lib.flags")
+    p = os.path.join(variant_paths(variant)[0], "lib.flags")
     return open(p).read() if os.path.exists(p) else None
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print("built", LIB)
+    var = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    print("built", build(force="--force" in sys.argv, variant=var))

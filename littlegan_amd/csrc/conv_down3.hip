@@ -75,6 +75,7 @@ struct D3Params {
   LgNormFuse nf;       // FUSE instantiation: norm-backward sums of the produced gradient (lg_common.h)
   int stagger;         // start delay of the odd-slot block in ~1024-cycle units
   unsigned long long* stamps;  // diagnostic build only (LG_D3_STAMPS): [block][64] s_memtime stamps of wave 0
+  int stamp_lite;              // only the block's first / last stamp (the per-phase stamps cost ~11 % and change the clock)
 };
 
 __device__ __forceinline__ int pix32(int r) {  // MFMA row -> tile pixel inside its 32-pixel group (see conv_halo.hip)
@@ -105,11 +106,13 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: the weight addresses stay in SGPRs
   const int wn = wid % NWV, wm = wid / NWV;                  // this wave: channels 32 wn .., pixel groups wm * NI ..
   const int G = gridDim.x;
-  const int lb = lg_xcd_remap(blockIdx.x, G);
-  const int nmine = (p.nitems - lb + G - 1) / G;  // items lb, lb + G, ...   (grid <= nitems)
   const int nchunk = p.Cs / KC;
+  // items lb, lb + G, ... (grid <= nitems).  Dealing the items out dynamically (a counter per XCD, first item static) was built
+  // and measured in round 3: it closes the 16 us gap between the two blocks of a CU (the older wave wins the matrix-pipe
+  // arbitration) to 5 us, but with 4 items of ~23 us per block the last block still ends one item late: kernel time unchanged.
+  const int lb = lg_xcd_remap(blockIdx.x, G);
+  const int nmine = (p.nitems - lb + G - 1) / G;
   const int total = nmine * nchunk;
-
   // ---- the (up to) 6 halo pieces this thread stages in every slice: LDS offset and position inside the halo ----------
   int pl[PPT], pyx[PPT];
 #pragma unroll
@@ -151,16 +154,23 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
     it.y0 = (tt / p.tpi_x) * TH; it.x0 = (tt % p.tpi_x) * TW;
     return it;
   };
+  // The halo pieces are fetched with RAW BUFFER loads from a descriptor over the item's sample(s): a piece outside the image
+  // (TF SAME padding), in a padding slot or beyond the thread's share gets an out-of-range offset and comes back as zeros.
+  // No branch surrounds a load.  (With `if (inside) v = load` hipcc branches around every load, can no longer count the loads
+  // in flight at the join, and falls back to `s_waitcnt vmcnt(4)` in front of the first taps of every other slice: the wave then
+  // sat out the HBM latency of the halo it had just requested — 1600 of a slice's 5100 cycles for a lone wave, r3 census.)
+  constexpr unsigned OOB = 0x80000000u;   // >= num_records for every supported shape (checked on the host)
+  const int sample_elems = p.Hs * p.Ws * p.Cs;
   auto issue = [&](const Item& it, int c0, u32x4 (&v)[PPT]) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(p.src + (long long)it.n * sample_elems), 0, (PAIR ? 2 : 1) * sample_elems * 2, 0x00027000);
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
-      v[u] = u32x4{0u, 0u, 0u, 0u};
-      if (pl[u] >= 0) {
-        const int sy = 2 * it.y0 - 1 + (pyx[u] >> 8), sx = 2 * it.x0 - 1 + (pyx[u] & (PAIR ? 127 : 255));
-        const int sn = it.n + (PAIR ? (pyx[u] >> 7) & 1 : 0);
-        if ((unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
-          v[u] = *reinterpret_cast<const u32x4*>(p.src + ((long long)(sn * p.Hs + sy) * p.Ws + sx) * p.Cs + c0 + half8);
-      }
+      const int sy = 2 * it.y0 - 1 + (pyx[u] >> 8), sx = 2 * it.x0 - 1 + (pyx[u] & (PAIR ? 127 : 255));
+      const int sl = PAIR ? (pyx[u] >> 7) & 1 : 0;   // PAIR: second sample of the tile
+      const bool ok = pl[u] >= 0 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+      const unsigned off = ok ? (unsigned)((((sl * p.Hs + sy) * p.Ws + sx) * p.Cs + c0 + half8) * 2) : OOB;
+      v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
   };
   auto commit = [&](char* buf, const u32x4 (&v)[PPT]) {
@@ -216,7 +226,15 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
 
 #ifdef LG_D3_STAMPS
   int nst = 0;
-#define D3_STAMP() do { if (p.stamps && wid == 0 && nst < 64) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) p.stamps[(long long)blockIdx.x * 64 + nst] = t_; ++nst; } } while (0)
+#define D3_STAMP() do { if (p.stamps && !p.stamp_lite && wid == 0 && nst < 60) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) p.stamps[(long long)blockIdx.x * 64 + nst] = t_; ++nst; } } while (0)
+  // residency census (diagnostic build only): where and when this block started — slot 61 = HW_ID | XCC_ID << 32, 62 / 63 = the
+  // chip-wide 100 MHz clock (s_memrealtime) at the block's start / end, comparable ACROSS blocks (s_memtime is per XCD)
+  if (p.stamps && wid == 0 && lane == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    p.stamps[(long long)blockIdx.x * 64 + 61] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+    p.stamps[(long long)blockIdx.x * 64 + 62] = __builtin_amdgcn_s_memrealtime();
+    p.stamps[(long long)blockIdx.x * 64 + 59] = __builtin_amdgcn_s_memtime();
+  }
 #else
 #define D3_STAMP() do {} while (0)
 #endif
@@ -437,6 +455,12 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
       if (s + 1 < total) slice(std::integral_constant<int, NTAP % RING>{}, s + 1);
     }
   }
+#ifdef LG_D3_STAMPS
+  if (p.stamps && wid == 0 && lane == 0) {
+    p.stamps[(long long)blockIdx.x * 64 + 60] = __builtin_amdgcn_s_memtime();
+    p.stamps[(long long)blockIdx.x * 64 + 63] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 }  // namespace
@@ -462,6 +486,7 @@ extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const 
   if (no64 < 0) no64 = getenv("LG_NO_DOWN3_N64") ? 1 : 0;
   const bool n64 = N % 128 != 0 && N % 64 == 0 && !pair && !no64;  // 64-column tiles (2 x 2 waves)
   if (((Hm % TH || Wm % TW) && !pair) || Cs % KC || (N % 128 && !n64) || B <= 0) return LG_ERR_UNSUPPORTED;
+  if ((long long)4 * Hm * Wm * Cs * 2 * 2 >= (1ll << 31)) return LG_ERR_UNSUPPORTED;  // buffer descriptor: two samples below the OOB offset
   D3Params p{};
   p.src = (const __bf16*)src16; p.wp = (const char*)wpack; p.bias = bias; p.out = (__bf16*)out16;
   p.B = B; p.Hm = Hm; p.Wm = Wm; p.Hs = 2 * Hm; p.Ws = 2 * Wm; p.Cs = Cs; p.N = N; p.N32 = N / 32; p.KB = Cs / 16;
@@ -471,7 +496,7 @@ extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const 
   p.nitems = (int)nitems; p.nparts = p.tpi * p.ntn;
   { static int stg = -1; if (stg < 0) { const char* e = getenv("LG_D3_STAGGER"); stg = e ? atoi(e) : 6; } p.stagger = stg; }
 #ifdef LG_D3_STAMPS
-  { const char* e = getenv("LG_D3_STAMPBUF"); p.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+  { const char* e = getenv("LG_D3_STAMPBUF"); p.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; p.stamp_lite = getenv("LG_D3_STAMPS_LITE") ? 1 : 0; }
 #endif
   const bool fuse = nf && nf->z && nf->stats && nf->part && nparts_out && (size_t)B * p.nparts * 2 * sizeof(double) <= nf_bytes;
   const bool stats = !fuse && spart && nparts_out && (size_t)B * p.nparts * 3 * sizeof(double) <= spart_bytes;
@@ -485,6 +510,7 @@ extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const 
       if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
     }
     nblk = 2 * cus;
+    if (const char* e = getenv("LG_D3_BLOCKS_PER_CU")) nblk = (atoi(e) > 0 ? atoi(e) : 2) * cus;  // probe: 1 = a lone wave per SIMD
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_down3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_down3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);

@@ -31,9 +31,16 @@ constexpr int RING = 8;
 #define LG_U3_SCHED 1   // 0: fragment step in three pinned groups; 1: interleaved by sched_group_barrier (MFMA, LDS read, ...)
 #endif
 
-template <int CS, int N> struct Cfg {
+// NTT = tiles per workgroup step.  Waves = NTT * WN * 4 classes: 8 (one workgroup per CU) or, for N = 32 with ONE tile per step,
+// 4 (TWO independent workgroups per CU, 58 KB of LDS each: one's staging / row-store / barrier phases fall into the other's
+// MFMA phase — r3 stamps of the 8-wave form at N = 32: 49 % of a step is not MFMA time and nothing overlaps it).
+template <int CS, int N, int NTT = 2 / (N / 32)> struct Cfg {
   static constexpr int WN = N / 32;               // column waves per tile (2 | 1)
-  static constexpr int NT = 2 / WN;               // tiles per workgroup step (1 | 2): 8 waves = NT * WN * 4 classes
+  static constexpr int NT = NTT;                  // tiles per workgroup step
+  static constexpr int NWAVES = NT * WN * 4, THREADS = 64 * NWAVES;
+  // 4-wave form: a wave's class ROTATES from step to step (order 3, 1, 0, 2): the waves of a workgroup sit on different SIMDs
+  // and the classes have 9 / 6 / 6 / 4 taps — fixed roles would leave one SIMD with 2.25 x the matrix work of another
+  static constexpr bool ROT = NWAVES == 4;
   static constexpr int PITCH = CS * 2 + 16;       // halo pixel pitch (bytes): consecutive pixels shift by one 16-B slot
   static constexpr int HB = NPX * PITCH;          // halo bytes per tile
   static constexpr int OPX = 4 * TH * TW;         // 512 output pixels per tile
@@ -42,11 +49,12 @@ template <int CS, int N> struct Cfg {
   static constexpr int KB = CS / 16;              // k-steps
   static constexpr int C_OFF = NT * HB;
   static constexpr int SRED_OFF = C_OFF + NT * CB;
-  static constexpr int SBIAS_OFF = SRED_OFF + 512 * 8;        // per-thread {sum d, sum d^2} floats of the current step
+  static constexpr int SBIAS_OFF = SRED_OFF + THREADS * 8;    // per-thread {sum d, sum d^2} floats of the current step
   static constexpr int LDS = SBIAS_OFF + N * 4;
   static constexpr int PIECES = NT * NPX * (CS * 2 / 16);       // 16-B halo pieces per step
-  static constexpr int PPT = (PIECES + 511) / 512;
+  static constexpr int PPT = (PIECES + THREADS - 1) / THREADS;
 };
+constexpr int rot_class(int i) { return (i & 3) == 0 ? 3 : (i & 3) == 1 ? 1 : (i & 3) == 2 ? 0 : 2; }
 
 struct U3Params {
   const __bf16* src;   // [B][Hs][Ws][CS]
@@ -72,10 +80,11 @@ constexpr int ntaps_of(int cls) { return nk(cls >> 1) * nk(cls & 1); }
 constexpr int tap_k(int p, int a) { return p ? 2 * a : 2 * a + 1; }
 constexpr int tap_d(int p, int a) { return (p + 1 - tap_k(p, a)) / 2; }
 
-template <int CS, int N, bool STATS, bool FUSE = false>
-__global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
+template <int CS, int N, bool STATS, bool FUSE = false, int NTT = 2 / (N / 32)>
+__global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel(const U3Params p) {
   static_assert(!(STATS && FUSE), "forward moments and backward sums are never needed together");
-  using C = Cfg<CS, N>;
+  using C = Cfg<CS, N, NTT>;
+  constexpr int NTH = C::THREADS, NWV = C::NWAVES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x2* sstat = reinterpret_cast<f32x2*>(smem + C::SRED_OFF);
   float* sbias = reinterpret_cast<float*>(smem + C::SBIAS_OFF);
@@ -86,8 +95,9 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
   const int wn = C::WN == 2 ? (wid & 1) : 0;
   const int tsel = C::WN == 2 ? 0 : (wid >> 2);                      // which of the NT tiles
   const int slot = C::WN == 2 ? (wid >> 1) : (wid & 3);
-  const int cls = C::WN == 2 ? (slot == 0 ? 3 : slot == 1 ? 1 : slot == 2 ? 0 : 2)
-                             : (tsel == 0 ? (slot == 0 ? 3 : slot == 1 ? 1 : slot == 2 ? 2 : 0) : (slot == 0 ? 0 : slot == 1 ? 2 : slot == 2 ? 1 : 3));
+  const int cls_fixed = C::WN == 2 ? (slot == 0 ? 3 : slot == 1 ? 1 : slot == 2 ? 0 : 2)
+                                   : (tsel == 0 ? (slot == 0 ? 3 : slot == 1 ? 1 : slot == 2 ? 2 : 0) : (slot == 0 ? 0 : slot == 1 ? 2 : slot == 2 ? 1 : 3));
+  int cls = C::ROT ? rot_class(wid) : cls_fixed;   // ROT: class of step s = rot_class(wid + s)
   const int G = gridDim.x;
   const int lb = lg_xcd_remap(blockIdx.x, G);
   const int nsteps_all = (p.nitems + C::NT - 1) / C::NT;       // steps (NT tiles each) over the whole problem
@@ -100,7 +110,7 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
   int pl[C::PPT], pyx[C::PPT];
 #pragma unroll
   for (int u = 0; u < C::PPT; ++u) {
-    const int q = tid + u * 512;
+    const int q = tid + u * NTH;
     pl[u] = -1; pyx[u] = 0;
     if (q < C::PIECES) {
       const int t = q / (NPX * PPR), rem = q - t * (NPX * PPR);
@@ -118,22 +128,29 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
     y0 = (tt / p.tpi_x) * TH; x0 = (tt % p.tpi_x) * TW;
     return true;
   };
+  // Halo pieces come through RAW BUFFER loads from a descriptor over the step's sample(s): a piece outside the image (SAME
+  // padding), of a tile that does not exist (odd tail) or beyond the thread's share gets an out-of-range offset and reads as
+  // zeros — NO branch around any load, so hipcc keeps an exact count of the loads in flight (with `if (inside) v = load` it
+  // loses the count at the join and drains the weight ring with s_waitcnt vmcnt(0) at every commit; see conv_down3.hip).
+  constexpr unsigned OOB = 0x80000000u;   // >= num_records for every supported shape (checked on the host)
+  const int sample_elems = p.Hs * p.Ws * CS;
   auto issue = [&](int step, u32x4 (&v)[C::PPT]) {
     int n[C::NT], y0[C::NT], x0[C::NT];
     bool ok[C::NT];
 #pragma unroll
     for (int t = 0; t < C::NT; ++t) ok[t] = tile_of(step, t, n[t], y0[t], x0[t]);
+    // the NT tiles of a step are consecutive items: the second one lies in the same sample or in the next
+    const int nrec = (p.B - n[0] >= 2 ? 2 : 1) * sample_elems * 2;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.src + (long long)n[0] * sample_elems), 0, nrec, 0x00027000);
 #pragma unroll
     for (int u = 0; u < C::PPT; ++u) {
-      v[u] = u32x4{0u, 0u, 0u, 0u};
-      if (pl[u] >= 0) {
-        const bool t1 = C::NT == 2 && (pyx[u] >> 20) != 0;  // selects, not runtime-indexed arrays (those go to scratch)
-        const int ty = t1 ? y0[C::NT - 1] : y0[0], tx = t1 ? x0[C::NT - 1] : x0[0], tn = t1 ? n[C::NT - 1] : n[0];
-        const bool tok = t1 ? ok[C::NT - 1] : ok[0];
-        const int sy = ty - 1 + ((pyx[u] >> 6) & 63), sx = tx - 1 + (pyx[u] & 63);
-        if (tok && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
-          v[u] = *reinterpret_cast<const u32x4*>(p.src + ((long long)(tn * p.Hs + sy) * p.Ws + sx) * CS + ((pyx[u] >> 12) & 255) * 8);
-      }
+      const bool t1 = C::NT == 2 && (pyx[u] >> 20) != 0;  // selects, not runtime-indexed arrays (those go to scratch)
+      const int ty = t1 ? y0[C::NT - 1] : y0[0], tx = t1 ? x0[C::NT - 1] : x0[0], dn = t1 ? n[C::NT - 1] - n[0] : 0;
+      const bool tok = t1 ? ok[C::NT - 1] : ok[0];
+      const int sy = ty - 1 + ((pyx[u] >> 6) & 63), sx = tx - 1 + (pyx[u] & 63);
+      const bool in = pl[u] >= 0 && tok && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+      const unsigned off = in ? (unsigned)((((dn * p.Hs + sy) * p.Ws + sx) * CS + ((pyx[u] >> 12) & 255) * 8) * 2) : OOB;
+      v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
   };
   auto commit = [&](const u32x4 (&v)[C::PPT]) {
@@ -185,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
   __syncthreads();
 
   // one class of one tile: F = taps * KB fragments, ring position OFF at entry (F % RING != 0 only for CS = 64, class 3)
-  auto run_class = [&](auto cls_c, auto off_c) {
+  auto run_class = [&](auto cls_c, auto off_c, auto next_c) {
     constexpr int CLS = decltype(cls_c)::value, OFF = decltype(off_c)::value;
     constexpr int PY = CLS >> 1, PX = CLS & 1, NKX = nk(PX), F = ntaps_of(CLS) * C::KB;
 #pragma unroll
@@ -215,7 +232,9 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
       for (int i = 0; i < 4; ++i)
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[sl]), a[f & 1][i], acc[i], 0, 0, 0);
       if constexpr (LG_U3_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
-      bf[sl] = *reinterpret_cast<const u32x4*>(frag_ptr(cls_c, (f + RING) % F));  // the stream wraps: same weights every tile
+      // the stream wraps: the same class every step — or (ROT) runs on into the first fragments of the wave's NEXT class
+      if (f + RING < F) bf[sl] = *reinterpret_cast<const u32x4*>(frag_ptr(cls_c, f + RING));
+      else bf[sl] = *reinterpret_cast<const u32x4*>(frag_ptr(next_c, f + RING - F));
       if constexpr (LG_U3_SCHED == 0) {
         __builtin_amdgcn_sched_barrier(0);
       } else {  // one MFMA, one LDS read in its shadow, ..., the ring refill behind the last MFMA (see conv_down3.hip)
@@ -231,27 +250,41 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
 
 #ifdef LG_U3_STAMPS
   int nst = 0;
-#define U3_STAMP() do { if (p.stamps && nst < 32) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) p.stamps[((long long)blockIdx.x * 8 + wid) * 32 + nst] = t_; ++nst; } } while (0)
+#define U3_STAMP() do { if (p.stamps && nst < 32) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) p.stamps[((long long)blockIdx.x * NWV + wid) * 32 + nst] = t_; ++nst; } } while (0)
 #else
 #define U3_STAMP() do {} while (0)
 #endif
   int roff = 0;  // ring position at the start of this wave's class (toggles 0 / 4 when F % RING == 4)
   for (int s = 0; s < nmine; ++s) {
     const bool more = s + 1 < nmine;
-    if (more) issue(s + 1, hv);
     int n, y0, x0;
     U3_STAMP();  // item start
     const bool live = tile_of(s, tsel, n, y0, x0);  // (N = 32: the second tile of the last step may not exist: computed, not stored)
 
-    if (cls == 3) {
-      if (roff == 0) run_class(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
-      else run_class(std::integral_constant<int, 3>{}, std::integral_constant<int, (RING / 2) % RING>{});
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>; using IH = std::integral_constant<int, (RING / 2) % RING>;
+    if constexpr (C::ROT) {
+      // rotation 3 -> 1 -> 0 -> 2 -> 3 ...; the ring position at a class's entry is 0 or RING / 2 (only the 9-tap class of the
+      // 64-channel form has a fragment count that is not a multiple of RING): both instantiations of every class
+      if (cls == 3) { if (roff == 0) run_class(I3{}, I0{}, I1{}); else run_class(I3{}, IH{}, I1{}); }
+      else if (cls == 1) { if (roff == 0) run_class(I1{}, I0{}, I0{}); else run_class(I1{}, IH{}, I0{}); }
+      else if (cls == 0) { if (roff == 0) run_class(I0{}, I0{}, I2{}); else run_class(I0{}, IH{}, I2{}); }
+      else { if (roff == 0) run_class(I2{}, I0{}, I3{}); else run_class(I2{}, IH{}, I3{}); }
+      roff = (roff + ntaps_of(cls) * C::KB) % RING;
+    } else if (cls == 3) {
+      if (roff == 0) run_class(I3{}, I0{}, I3{});
+      else run_class(I3{}, IH{}, I3{});
       roff = (roff + ntaps_of(3) * C::KB) % RING;
-    } else if (cls == 2) run_class(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
-    else if (cls == 1) run_class(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-    else run_class(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    } else if (cls == 2) run_class(I2{}, I0{}, I2{});
+    else if (cls == 1) run_class(I1{}, I0{}, I1{});
+    else run_class(I0{}, I0{}, I0{});
 
     U3_STAMP();  // class computed
+    // The next step's halo is requested HERE, behind the MFMA stream, and lands under the staging pass and the barrier below.
+    // (vmcnt retires in order: requested at the top of the step, these HBM loads sat in front of the weight ring's refills and
+    //  every ring wait of the first fragments also waited for them.)  Last step: the current halo again — valid addresses, result
+    // unused, no branch around the loads.
+    issue(more ? s + 1 : s, hv);
     // ---- this wave's class into the output-tile staging area: acc[i][e] = channel (e&3) + 8*(e>>2) + 4*h of pixel m ----------
     {
       char* Cst = smem + C::C_OFF + tsel * C::CB;
@@ -295,12 +328,12 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
     constexpr int TOT = C::NT * C::OPX * PPO;         // 4096 pieces per step either way
     // FUSE: the z pieces this thread will meet in the row sweep are requested NOW — the accumulators are dead (staged), and
     // the loads land behind the barrier and the halo commit instead of in front of every use
-    u32x4 zq[FUSE ? TOT / 512 : 1];
+    u32x4 zq[FUSE ? TOT / NTH : 1];
     (void)zq;
     if constexpr (FUSE) {
 #pragma unroll
-      for (int q8 = 0; q8 < TOT / 512; ++q8) {
-        const int q = tid + q8 * 512;
+      for (int q8 = 0; q8 < TOT / NTH; ++q8) {
+        const int q = tid + q8 * NTH;
         const int t = q / (C::OPX * PPO), rem = q - t * (C::OPX * PPO);
         const int o = rem / PPO, j = rem - o * PPO;
         const bool t1 = C::NT == 2 && t != 0;
@@ -319,8 +352,8 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
       float nf1 = 0.f, nf2 = 0.f;
       (void)nf1; (void)nf2;
 #pragma unroll
-      for (int q8 = 0; q8 < TOT / 512; ++q8) {
-        const int q = tid + q8 * 512;
+      for (int q8 = 0; q8 < TOT / NTH; ++q8) {
+        const int q = tid + q8 * NTH;
         const int t = q / (C::OPX * PPO), rem = q - t * (C::OPX * PPO);
         const int o = rem / PPO, j = rem - o * PPO;
         const bool t1 = C::NT == 2 && t != 0;
@@ -340,12 +373,12 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
     }
     if constexpr (FUSE) {
       __syncthreads();
-      const int t = wid / (8 / C::NT);
-      if (wid == t * (8 / C::NT)) {
+      const int t = wid / (NWV / C::NT);
+      if (wid == t * (NWV / C::NT)) {
         double S1 = 0.0, S2 = 0.0;
 #pragma unroll
-        for (int w = 0; w < 8 / C::NT; ++w) {
-          const f32x2 v = sstat[(t * (8 / C::NT) + w) * 64 + lane];
+        for (int w = 0; w < NWV / C::NT; ++w) {
+          const f32x2 v = sstat[(t * (NWV / C::NT) + w) * 64 + lane];
           S1 += (double)v[0]; S2 += (double)v[1];
         }
         S1 = lg_wave_sum_d(S1); S2 = lg_wave_sum_d(S2);
@@ -361,12 +394,12 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
     if constexpr (STATS) {
       // the first wave of each tile adds the per-thread partials of that tile's waves (fp64 from here on) while the other
       // waves are still writing rows: one cross-lane reduction per tile instead of one per wave
-      const int t = wid / (8 / C::NT);
-      if (wid == t * (8 / C::NT)) {
+      const int t = wid / (NWV / C::NT);
+      if (wid == t * (NWV / C::NT)) {
         double S1 = 0.0, S2 = 0.0;
 #pragma unroll
-        for (int w = 0; w < 8 / C::NT; ++w) {
-          const f32x2 v = sstat[(t * (8 / C::NT) + w) * 64 + lane];
+        for (int w = 0; w < NWV / C::NT; ++w) {
+          const f32x2 v = sstat[(t * (NWV / C::NT) + w) * 64 + lane];
           S1 += (double)v[0]; S2 += (double)v[1];
         }
         S1 = lg_wave_sum_d(S1); S2 = lg_wave_sum_d(S2);
@@ -384,13 +417,14 @@ __global__ __launch_bounds__(512, 2) void conv_up3_kernel(const U3Params p) {
     }
     (void)live;
     U3_STAMP();  // rows out
+    if constexpr (C::ROT) cls = rot_class(wid + s + 1);
     __syncthreads();  // next halo complete, staging area free again
   }
 }
 
-template <int CS, int N>
+template <int CS, int N, int NTT = 2 / (N / 32)>
 int launch_up3(U3Params p, bool stats, hipStream_t st, bool fuse = false) {
-  using C = Cfg<CS, N>;
+  using C = Cfg<CS, N, NTT>;
   static int nblk = 0;
   if (!nblk) {
     int dev = 0, cus = 256;
@@ -398,16 +432,16 @@ int launch_up3(U3Params p, bool stats, hipStream_t st, bool fuse = false) {
       hipDeviceProp_t pr;
       if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
     }
-    nblk = cus;  // one 8-wave workgroup per CU
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, true>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    nblk = (C::NWAVES == 8 ? 1 : 2) * cus;  // one 8-wave workgroup per CU, or two independent 4-wave ones
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, true, false, NTT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false, false, NTT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false, true, NTT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
   }
   const int nsteps = (p.nitems + C::NT - 1) / C::NT;
   const int grid = nsteps < nblk ? nsteps : nblk;
-  if (fuse) hipLaunchKernelGGL((conv_up3_kernel<CS, N, false, true>), dim3(grid), dim3(512), C::LDS, st, p);
-  else if (stats) hipLaunchKernelGGL((conv_up3_kernel<CS, N, true>), dim3(grid), dim3(512), C::LDS, st, p);
-  else hipLaunchKernelGGL((conv_up3_kernel<CS, N, false>), dim3(grid), dim3(512), C::LDS, st, p);
+  if (fuse) hipLaunchKernelGGL((conv_up3_kernel<CS, N, false, true, NTT>), dim3(grid), dim3(C::THREADS), C::LDS, st, p);
+  else if (stats) hipLaunchKernelGGL((conv_up3_kernel<CS, N, true, false, NTT>), dim3(grid), dim3(C::THREADS), C::LDS, st, p);
+  else hipLaunchKernelGGL((conv_up3_kernel<CS, N, false, false, NTT>), dim3(grid), dim3(C::THREADS), C::LDS, st, p);
   return LG_OK;
 }
 
@@ -432,6 +466,7 @@ extern "C" int lg_conv_up3_nf_try(const void* src16, const void* wpack_up, const
                                   size_t nf_bytes, void* stream) {
   if (nparts_out) *nparts_out = 0;
   if (!src16 || !wpack_up || !out16 || !lg_conv_up3_supported(B, Hm, Wm, Cs, N)) return LG_ERR_UNSUPPORTED;
+  if ((long long)Hm * Wm * Cs * 2 * 2 >= (1ll << 31)) return LG_ERR_UNSUPPORTED;  // buffer descriptor: two samples below the OOB offset
   U3Params p{};
   p.src = (const __bf16*)src16; p.wp = (const char*)wpack_up; p.bias = bias; p.out = (__bf16*)out16;
   p.B = B; p.Hs = Hm; p.Ws = Wm; p.tpi_x = Wm / TW; p.tpi = p.tpi_x * (Hm / TH);
@@ -441,17 +476,22 @@ extern "C" int lg_conv_up3_nf_try(const void* src16, const void* wpack_up, const
 #ifdef LG_U3_STAMPS
   { const char* e = getenv("LG_U3_STAMPBUF"); p.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
 #endif
-  // the norm-backward sums are produced by the (128, 64) form only: with two tiles per step (N = 32) a thread's row sweep covers
+  // N = 32: two independent 4-wave workgroups per CU, one tile per step (LG_U3_T4_8W=1: the round-2 form, one 8-wave workgroup
+  // with two tiles per step)
+  static int t4_8w = -1;
+  if (t4_8w < 0) t4_8w = getenv("LG_U3_T4_8W") ? 1 : 0;
+  // the norm-backward sums are produced by the one-tile-per-step forms only: with two tiles per step a thread's row sweep covers
   // both tiles, i.e. possibly two samples, and the per-thread sums would mix them (no layer of the step asks for that form)
-  const bool fuse = Cs == 128 && nf && nf->z && nf->stats && nf->part && nparts_out && (size_t)B * p.tpi * 2 * sizeof(double) <= nf_bytes;
+  const bool fuse = (Cs == 128 || !t4_8w) && nf && nf->z && nf->stats && nf->part && nparts_out && (size_t)B * p.tpi * 2 * sizeof(double) <= nf_bytes;
   const bool stats = !fuse && spart && nparts_out && (size_t)B * p.tpi * 3 * sizeof(double) <= spart_bytes;
   p.spart = stats ? (double*)spart : nullptr;
   if (fuse) p.nf = *nf;
   hipStream_t st = (hipStream_t)stream;
   if (Cs == 128) launch_up3<128, 64>(p, stats, st, fuse);
-  else launch_up3<64, 32>(p, stats, st, fuse);
+  else if (t4_8w) launch_up3<64, 32>(p, stats, st, fuse);
+  else launch_up3<64, 32, 1>(p, stats, st, fuse);
   LG_CHECK_LAUNCH("lg_conv_up3");
-  lg_note_kernel(Cs == 128 ? "conv_up3_kernel<128,64>" : "conv_up3_kernel<64,32>");
+  lg_note_kernel(Cs == 128 ? "conv_up3_kernel<128,64>" : t4_8w ? "conv_up3_kernel<64,32>" : "conv_up3_kernel<64,32,4w>");
   if (stats || fuse) *nparts_out = p.tpi;
   return LG_OK;
 }

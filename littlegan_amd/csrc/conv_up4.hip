@@ -103,16 +103,21 @@ __device__ __forceinline__ void up4_run(const U4Params& p, char* smem, int lb, i
     it.y0 = (tt / p.tpi_x) * TH; it.x0 = (tt % p.tpi_x) * TW;
     return it;
   };
+  // RAW BUFFER loads from a descriptor over the item's sample: a piece outside the image (SAME padding) or beyond the thread's
+  // share gets an out-of-range offset and reads as zeros — no branch around any load, so hipcc keeps an exact count of the loads
+  // in flight (conv_down3.hip: with `if (inside) v = load` it fell back to short vmcnt waits that exposed the halo's HBM latency)
+  constexpr unsigned OOB = 0x80000000u;   // >= num_records for every supported shape (checked on the host)
+  const int sample_elems = p.Hs * p.Ws * p.Cs;
   auto issue = [&](const Item& it, int c0, u32x4 (&v)[PPT]) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.src + (long long)it.n * sample_elems), 0,
+                                                                        sample_elems * 2, 0x00027000);
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
-      v[u] = u32x4{0u, 0u, 0u, 0u};
-      if (pl[u] >= 0) {
-        const int pq = pyx[u] + (int)wzero;  // (re-derived per slice: hoisted out of the slice loop these offsets spill)
-        const int sy = it.y0 - 1 + ((pq >> 8) & 255), sx = it.x0 - 1 + (pq & 255);
-        if ((unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
-          v[u] = *reinterpret_cast<const u32x4*>(p.src + ((long long)(it.n * p.Hs + sy) * p.Ws + sx) * p.Cs + c0 + (pq >> 16) * 8);
-      }
+      const int pq = pyx[u] + (int)wzero;  // (re-derived per slice: hoisted out of the slice loop these offsets spill)
+      const int sy = it.y0 - 1 + ((pq >> 8) & 255), sx = it.x0 - 1 + (pq & 255);
+      const bool in = pl[u] >= 0 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+      const unsigned off = in ? (unsigned)(((sy * p.Ws + sx) * p.Cs + c0 + (pq >> 16) * 8) * 2) : OOB;
+      v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
   };
   auto commit = [&](char* buf, const u32x4 (&v)[PPT]) {
@@ -310,7 +315,8 @@ __global__ __launch_bounds__(256, 2) void conv_up4_kernel(const U4Params p) {
 }  // namespace
 
 extern "C" int lg_conv_up4_supported(int B, int Hm, int Wm, int Cs, int N) {
-  return (!getenv("LG_NO_UP4") && B > 0 && Hm % TH == 0 && Wm % TW == 0 && Cs % KC == 0 && N % 128 == 0) ? 1 : 0;
+  return (!getenv("LG_NO_UP4") && B > 0 && Hm % TH == 0 && Wm % TW == 0 && Cs % KC == 0 && N % 128 == 0 &&
+          (long long)Hm * Wm * Cs * 2 < (1ll << 31)) ? 1 : 0;   // (one sample below the out-of-range offset of the halo loads)
 }
 
 // LG_OK: launched.  LG_ERR_UNSUPPORTED: the caller falls back to conv_halo.hip.  Hm, Wm: the SOURCE (small) map.

@@ -16,9 +16,12 @@ w = torch.randn(5, 5, cb, cs, device="cuda") * 0.05
 pack = ops.conv_pack(w, cb, cs, dt)
 x16 = torch.randn(B, Hs, Hs, cs, device="cuda").to(torch.bfloat16)
 bias = torch.zeros(cb, device="cuda")
-for _ in range(3):
-    ops.convT_s2_fwd_stats(None, pack, bias, cb, dt, gm, bt, x16=x16, z16=True)
-torch.cuda.synchronize()
+import time
+t_end = time.time() + 2.0   # the clock the chip holds under the kernel, not its ramp from idle
+while time.time() < t_end:
+    for _ in range(50):
+        ops.convT_s2_fwd_stats(None, pack, bias, cb, dt, gm, bt, x16=x16, z16=True)
+    torch.cuda.synchronize()
 st = buf.view(256, 8, 32).cpu().numpy()
 names = ["start", "class", "staged", "bar1", "rows", "(bar2+next start)"]
 for b in (0, 100):
@@ -28,4 +31,14 @@ for b in (0, 100):
         d = [int(row[i] - row[i - 1]) for i in range(1, min(n, 16))]
         print(f"block {b} wave {w}: {d}")
 print("stamp order per item:", names)
+import numpy as np
+# per wave role: median cycles of each phase over all blocks and items (5 stamps per item)
+for w in range(8):
+    ph = [[] for _ in range(5)]
+    for b in range(256):
+        row = st[b, w]; n = int((row > 0).sum())
+        d = np.diff(row[:n])
+        for i in range(len(d)):
+            ph[i % 5].append(d[i])
+    print(f"wave {w}: median cycles  compute {np.median(ph[0]):.0f}  stage {np.median(ph[1]):.0f}  wait-barrier1 {np.median(ph[2]):.0f}  commit+rows {np.median(ph[3]):.0f}  barrier2+issue {np.median(ph[4]):.0f}   item total {sum(np.median(x) for x in ph):.0f}")
 print("block 0 wave 0 total cycles:", int(st[0, 0][st[0, 0] > 0].max() - st[0, 0, 0]))
