@@ -484,6 +484,9 @@ extern "C" int lg_conv_up3_nf_try(const void* src16, const void* wpack_up, const
   // both tiles, i.e. possibly two samples, and the per-thread sums would mix them (no layer of the step asks for that form)
   const bool fuse = (Cs == 128 || !t4_8w) && nf && nf->z && nf->stats && nf->part && nparts_out && (size_t)B * p.tpi * 2 * sizeof(double) <= nf_bytes;
   const bool stats = !fuse && spart && nparts_out && (size_t)B * p.tpi * 3 * sizeof(double) <= spart_bytes;
+  // moments asked for (the caller may then write z as bf16 ONLY) but the workspace cannot hold this tiling's records: decline, so
+  // that the dispatch chain tries the next kernel instead of launching without them (lg_conv_fwd_stats_fused's promise)
+  if (!nf && spart && nparts_out && !stats) return LG_ERR_UNSUPPORTED;
   p.spart = stats ? (double*)spart : nullptr;
   if (fuse) p.nf = *nf;
   hipStream_t st = (hipStream_t)stream;

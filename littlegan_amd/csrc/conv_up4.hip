@@ -337,6 +337,9 @@ extern "C" int lg_conv_up4_nf_try(const void* src16, const void* wpack_up, const
   p.nper = (int)nper; p.nparts = p.tpi * 4 * p.ntn;
   const bool fuse = nf && nf->z && nf->stats && nf->part && nparts_out && (size_t)B * p.nparts * 2 * sizeof(double) <= nf_bytes;
   const bool stats = !fuse && spart && nparts_out && (size_t)B * p.nparts * 3 * sizeof(double) <= spart_bytes;
+  // moments asked for (the caller may then write z as bf16 ONLY) but the workspace cannot hold this tiling's records: decline, so
+  // that the dispatch chain tries the next kernel instead of launching without them (lg_conv_fwd_stats_fused's promise)
+  if (!nf && spart && nparts_out && !stats) return LG_ERR_UNSUPPORTED;
   p.spart = stats ? (double*)spart : nullptr;
   if (fuse) p.nf = *nf;
   static int nblk = 0;

@@ -336,10 +336,31 @@ class EagerTrainer:
         a = self.args
         tdir = getattr(a, "test_data_dir", None)
         npz = os.path.join(tdir, "test_data_" + str(getattr(a, "env", "default")) + ".npz") if tdir else None
-        if npz and os.path.isfile(npz) and getattr(a, "reuse", False):
+
+        def usable(path):
+            """a complete file of THIS configuration (the reference regenerates when the shapes do not fit, :77-80)"""
+            try:
+                with np.load(path) as d:
+                    n, c, i = d["n"], d["c"], d["i"]
+                H = a.init_dim * 16
+                return (n.shape == (a.batch_size, a.noise_dim) and c.shape == (a.batch_size, a.cond_dim)
+                        and i.shape == (a.batch_size, H, H, a.image_channel))
+            except Exception:
+                return False
+
+        # data parallel: ONE decision for all ranks (rank 0 looks, the others are told) — a rank that finds rank 0's half-
+        # written file, or loads while others generate, would leave the dataset generators of the ranks one draw apart
+        load = bool(npz and getattr(a, "reuse", False) and os.path.isfile(npz) and usable(npz)) if self.rank == 0 else False
+        if self.world > 1:
+            flag = [load]
+            torch.distributed.broadcast_object_list(flag, src=0)
+            load = flag[0]
+        if load:
             data = np.load(npz)
             to = lambda v: torch.tensor(np.asarray(v, np.float32), device=self.device)
             self.test_noise, self.test_cond, self.test_image = to(data["n"]), to(data["c"]), to(data["i"])
+            if self.dataset is not None:
+                self.dataset.get_new_iterator()   # the generating path draws one epoch order: keep every path's generator in step
             return
         if self.dataset is None:
             return
@@ -351,8 +372,11 @@ class EagerTrainer:
         self.test_noise = ops.randn((self.test_cond.shape[0], a.noise_dim), seed, 0, device=self.device)
         if npz and self.rank == 0 and not getattr(a, "no_io", False):
             os.makedirs(tdir, exist_ok=True)
-            np.savez_compressed(npz, n=self.test_noise.cpu().numpy(), c=self.test_cond.cpu().numpy(),
+            tmp = npz + ".tmp.npz"   # written whole, then renamed: no reader ever sees a partial file
+            np.savez_compressed(tmp, n=self.test_noise.cpu().numpy(), c=self.test_cond.cpu().numpy(),
                                 i=self.test_image.cpu().numpy())
+            os.replace(tmp, npz)
+        _barrier()
 
     # ---- checkpoints (own format: the TF checkpoint format is out of scope, the CONTENT is the reference's:
     # tf.train.Checkpoint(discriminator, generator, adjuster, three optimizers) eager_trainer.py:31-35)

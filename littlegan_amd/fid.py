@@ -57,3 +57,45 @@ def fid_from_activations(act_a: torch.Tensor, act_b: torch.Tensor) -> float:
     m1, s1 = activation_statistics(act_a)
     m2, s2 = activation_statistics(act_b)
     return frechet_distance(m1, s1, m2, s2)
+
+
+# ------------------------------------------------------------------ evaluate.py:29-59 on saved activations
+def load_activations(path: str) -> torch.Tensor:
+    """[N, D] float32 Inception pool_3 activations from `path`: an .npy / .npz file (key "act", else its first array), or a
+    directory holding activations.npy.  The reference computes them from the JPEGs of `image_path` with a frozen Inception graph
+    it downloads (evaluate.py:45-46,53-55, fid.py:36-106,276); that graph cannot be obtained in this pipeline, so the entry points
+    below start from the activations a user has saved."""
+    import os
+    if os.path.isdir(path):
+        path = os.path.join(path, "activations.npy")
+    a = np.load(path)
+    if hasattr(a, "files"):
+        a = a["act"] if "act" in a.files else a[a.files[0]]
+    a = np.asarray(a, np.float32)
+    if a.ndim != 2 or a.shape[0] < 2:
+        raise ValueError(f"{path}: need an [N >= 2, D] activation matrix, got {a.shape}")
+    t = torch.from_numpy(a)
+    return t.cuda() if torch.cuda.is_available() else t
+
+
+def pre_calculate(act_path: str, stats_path: str):
+    """evaluate.py `pre-calculate` (:29-42): statistics of the real images' activations -> stats npz {mu, sigma}."""
+    mu, sigma = activation_statistics(load_activations(act_path))
+    np.savez_compressed(stats_path, mu=mu, sigma=sigma)
+    print("finished")
+    return mu, sigma
+
+
+def calc(act_path: str, stats_path: str, output_file: str) -> float:
+    """evaluate.py `calc` (:43-59): statistics of the generated images' activations (on the device: lg_fid_stats), the Frechet
+    distance to the pre-calculated statistics, "FID: <value>" on stdout and one line appended to the log in the reference's
+    format ("\\n <iso time> <value>\\n ")."""
+    import datetime
+    with np.load(stats_path) as f:
+        mu_real, sigma_real = f["mu"][:], f["sigma"][:]
+    mu_gen, sigma_gen = activation_statistics(load_activations(act_path))
+    fid_value = frechet_distance(mu_gen, sigma_gen, mu_real, sigma_real)
+    print("FID: %s" % fid_value)
+    with open(output_file, "a") as f:
+        print("\n", datetime.datetime.now().isoformat(), fid_value, end="\n ", file=f)
+    return fid_value

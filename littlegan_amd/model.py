@@ -229,7 +229,11 @@ class Decoder(_ConvStack):
     def _bias_dim(cb, cs):
         return cb
 
-    def __call__(self, inputs, ctx: Optional[dict] = None):
+    def __call__(self, inputs, ctx: Optional[dict] = None, raw_last: bool = False):
+        """raw_last (bf16 path, when the final layer can normalise while it stages — ops.convT_s1_tanh_fwd_z16_supported): the
+        last level's InstanceNorm + LeakyReLU pass is NOT run; returns (None, None) and leaves that level's raw (z16, stats) in
+        ctx["dec"][3] for the consumer.  Only for callers whose tapes never need the normalised level-4 map: it is the operand
+        of the final layer's WEIGHT gradient, so the Generator keeps it; the Adjuster (trains its dense + norm only) does not."""
         x, add = inputs
         a = self.args.leaky_alpha
         packs = self.packs()
@@ -255,6 +259,10 @@ class Decoder(_ConvStack):
             else:
                 drop32 = want16 = m16 and ops.n3_m16_supported(z.shape[1], z.shape[2], self.args.image_channel, cb,
                                                                self.dtype)
+            if i == 4 and raw_last and m16 and z.dtype == torch.bfloat16:
+                saved.append((x, z, st, x16))
+                x, x16 = None, None
+                break
             h16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if want16 else None
             if isinstance(skip, tuple):  # skip given as (first rows, remaining rows) of the batch: one apply per part
                 b1 = skip[0].shape[0]
@@ -326,6 +334,15 @@ class _FinalConv(_Module):
 
     def __call__(self, x, out=None, x16=None):
         return ops.convT_s1_tanh_fwd(x, self.pack(), self._w["bias"], self.cb, self.dtype, out=out, x16=x16)
+
+    def raw_supported(self, H, W):
+        """the layer can take the decoder's RAW last map + its statistics (normalisation applied while staging)"""
+        return self.dtype == DT_BF16 and ops.convT_s1_tanh_fwd_z16_supported(H, W, self.cb, self.cs, self.dtype)
+
+    def from_raw(self, z16, stats, out=None):
+        """tanh(convT_s1(LeakyReLU(InstanceNorm(z)))) with the normalised map never written (lg_convT_s1_tanh_fwd_z16,
+        bit-identical to apply + conv: tests/test_ops_gpu.py)"""
+        return ops.convT_s1_tanh_fwd_z16(z16, stats, self.args.leaky_alpha, self.pack(), self._w["bias"], self.cb, self.dtype, out=out)
 
     def backward(self, x, dpre, need_wgrad: bool, x16=None, need_dx: bool = True, fuse=None):
         """Returns dL/dx: fp32, or bf16 in the bf16 path (the decoder's norm backward reads either); None if not need_dx.
@@ -539,8 +556,16 @@ class Adjuster(_Module):
             own = cond.shape[0] - enc_tails[0].shape[0]
             enc = self.encoder(image[:own], None, tails=enc_tails)
         c4 = self._dn(cond.contiguous(), ctx)
-        x, x16 = self.decoder([c4, enc[::-1]], ctx)
-        img = self.conv(x, x16=x16)
+        # the Adjuster's tape differentiates dense + norm only (eager_trainer.py:51,62,163): nothing ever reads the decoder's
+        # normalised last map again, so the final layer takes the raw map and normalises while it stages (bf16 path)
+        side = self.args.init_dim * 16
+        raw = self.conv.raw_supported(side, side)
+        dctx = ctx if ctx is not None else ({} if raw else None)
+        x, x16 = self.decoder([c4, enc[::-1]], dctx, raw_last=raw)
+        if raw and x is None and x16 is None:
+            img = self.conv.from_raw(dctx["dec"][3][1], dctx["dec"][3][2])
+        else:
+            img = self.conv(x, x16=x16)
         if ctx is not None:
             ctx["xdec"], ctx["xdec16"], ctx["img"] = x, x16, img
         return img

@@ -1,6 +1,8 @@
 """CLI mirror of /root/reference/main.py on the HIP hot path:  python main.py <mode> <exp_name> [-e env] [-g gpus] [--debug]
-Modes kept: train, random-sample, condition-sample, evaluate-sample, export-model.  `visual` (tensorboard), `plot`
-(pydot) and `evaluate` (FID / Inception download) are UI / evaluation tooling outside the hot path."""
+Modes kept: train, random-sample, condition-sample, evaluate-sample, evaluate, export-model.  `evaluate` runs the FID
+arithmetic (main.py:82-104 -> evaluate.py calc) on SAVED Inception activations of the evaluate-sample images: the frozen
+Inception graph the reference downloads cannot be obtained here.  `visual` (tensorboard) and `plot` (pydot) are UI tooling
+outside the hot path."""
 import os
 import time
 
@@ -75,6 +77,14 @@ elif args.mode == "evaluate-sample":
             if adj_real is not None and adj_fake is not None:
                 save_image(adj_real[i], path.join(args.result_dir, "evaluate", "adj", "real_" + str(base_index + i) + ".jpg"))
                 save_image(adj_fake[i], path.join(args.result_dir, "evaluate", "adj", "fake_" + str(base_index + i) + ".jpg"))
+elif args.mode == "evaluate":
+    # main.py:82-104: FID of the evaluate-sample images (gen, and adj when the Adjuster is trained) against the pre-calculated
+    # statistics <test_data_dir>/<evaluate_pre_calculated>; one log line per call in evaluate/fid-{gen,adj}.log
+    from littlegan_amd import fid
+    for kind in ["gen"] + (["adj"] if args.train_adj else []):
+        print("Running: \"evaluate calc %s\"" % kind)
+        fid.calc(path.join(args.result_dir, "evaluate", kind), path.join(args.test_data_dir, args.evaluate_pre_calculated),
+                 path.join(args.result_dir, "evaluate", "fid-%s.log" % kind))
 elif args.mode == "condition-sample":
     args.reuse = True
     model = EagerTrainer(args, generator, discriminator, adjuster, None)

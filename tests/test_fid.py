@@ -70,3 +70,26 @@ def test_in_tree_covariance_kernel_matches_numpy(N, D):
     ref = np.cov(an, rowvar=False)
     assert np.abs(sigma.cpu().numpy() - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
     assert torch.equal(sigma, sigma.t())
+
+
+def test_evaluate_calc_on_saved_activations(tmp_path):
+    """evaluate.py:29-59 on saved activations: pre-calculate writes {mu, sigma}; calc prints / returns the Frechet distance and
+    appends one line in the reference's log format; identical activations give 0, a shifted set its closed form."""
+    from littlegan_amd import fid
+    rng = np.random.default_rng(5)
+    real = rng.standard_normal((300, 16)).astype(np.float32)
+    np.save(tmp_path / "real.npy", real)
+    gen_dir = tmp_path / "gen"
+    gen_dir.mkdir()
+    shift = np.zeros(16, np.float32)
+    shift[3] = 2.0
+    np.save(gen_dir / "activations.npy", real + shift)          # same covariance, mean moved by 2 in one coordinate
+    stats = str(tmp_path / "stats.npz")
+    mu, sigma = fid.pre_calculate(str(tmp_path / "real.npy"), stats)
+    assert np.abs(mu - real.astype(np.float64).mean(0)).max() < 1e-6 and sigma.shape == (16, 16)
+    log = str(tmp_path / "fid.log")
+    assert abs(fid.calc(str(tmp_path / "real.npy"), stats, log)) < 1e-6
+    v = fid.calc(str(gen_dir), stats, log)
+    assert abs(v - 4.0) < 1e-4
+    lines = [ln for ln in open(log).read().split("\n") if ln.strip()]
+    assert len(lines) == 2 and abs(float(lines[1].split()[-1]) - v) < 1e-9
