@@ -51,8 +51,8 @@ def short(name):
     t = lambda i, d=None: a[i] if i < len(a) else d
     if base == "conv_down3_kernel":      # <STATS, FUSE, PAIR = false, NW = 128>
         return "conv_down3_kernel<PAIR>" if t(2) == "true" else f"conv_down3_kernel<NW={t(3, '128')}>"
-    if base == "conv_up3_kernel":        # <CS, N, STATS, FUSE>
-        return f"conv_up3_kernel<{t(0)},{t(1)}>"
+    if base == "conv_up3_kernel":        # <CS, N, STATS, FUSE, NTT = tiles per step>; (64, 32) with one tile per step = the 4-wave form
+        return f"conv_up3_kernel<{t(0)},{t(1)}" + (",4w>" if (t(1) == "32" and t(4, "2") == "1") else ">")
     if base == "conv_halo_kernel":       # <T, MODE, KCH, DBUF, SRC16, RES, ...>
         ty = "bf16" if t(0) == "__bf16" else "f32"
         mode = t(1)

@@ -16,6 +16,9 @@ CASES = [
     ("conv_down3_kernel<true, false, true, 128>", "conv_down3_kernel<PAIR>"),
     ("conv_up3_kernel<128, 64, false, true>", "conv_up3_kernel<128,64>"),
     ("void (anonymous namespace)::conv_up3_kernel<64, 32, true, false>((anonymous namespace)::U3Params)", "conv_up3_kernel<64,32>"),
+    ("conv_up3_kernel<64, 32, true, false, 1>", "conv_up3_kernel<64,32,4w>"),
+    ("conv_up3_kernel<64, 32, true, false, 2>", "conv_up3_kernel<64,32>"),
+    ("conv_up3_kernel<128, 64, false, true, 1>", "conv_up3_kernel<128,64>"),
     ("conv_up4_kernel<true, false>", "conv_up4_kernel"),
     ("wgrad_at_kernel<16, 8>", "wgrad_at_kernel<16,8>"),
     ("patch_p16_kernel<1, 32, true, false, true>", "patch_p16_kernel<1,32,nf>"),
