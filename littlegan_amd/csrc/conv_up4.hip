@@ -28,8 +28,18 @@ constexpr int TH = 8, TW = 16, HHT = TH + 2, HWT = TW + 2, NPX = HHT * HWT;  // 
 constexpr int KC = 64, KS = KC / 16;          // channels per slice, k-steps per tap and slice
 constexpr int PITCH = KC * 2 + 16;            // 144 B per halo pixel: 16 consecutive pixels hit 16 distinct 16-B slots
 constexpr int HB = 32768;                     // buffer size: the halo slice (25920 B) or the 128 x 256-B output tile
-constexpr int NPIECE = NPX * (KC / 8);        // 1440 16-B pieces per slice
-constexpr int PPT = (NPIECE + 255) / 256;     // 6
+// PAIR (8 x 8 source maps, even batch): a tile = TWO samples side by side (class-pixel columns 0..7 = sample n, 8..15 = sample n + 1),
+// each with its own 10 x 10 halo.  Both halos use a 10-slot row pitch (tap offsets stay compile-time constants) and sample 1's
+// image starts 104 slots behind sample 0's: a ds_read_b128 lane group is one tile row = 8 pixels of each sample, and with a
+// 144-B pitch the 16 slots of 8 + 8 consecutive pixels are distinct exactly when the two runs are 8 (mod 16) slots apart
+// (100 slots of sample 0 + 4 spare; side by side in one 20-slot row, pixels p and p + 16 would share their banks).
+constexpr int PHW = 10, PNPX = 100, PS1 = 104;
+template <bool PAIR> struct U4L {
+  static constexpr int HWP = PAIR ? PHW : HWT;                       // halo row pitch in pixel slots
+  static constexpr int NPIECE = (PAIR ? 2 * PNPX : NPX) * (KC / 8);  // 16-B pieces per slice (1600 | 1440)
+  static constexpr int PPT = (NPIECE + 255) / 256;                   // 7 | 6
+};
+static_assert((PS1 + PNPX) * PITCH <= HB, "pair halo fits the buffer");
 constexpr int SRED_OFF = 2 * HB, SBIAS_OFF = 2 * HB + 256, LDS_BYTES = 2 * HB + 256 + 512;
 
 struct U4Params {
@@ -57,11 +67,12 @@ constexpr int ntaps_of(int cls) { return nk(cls >> 1) * nk(cls & 1); }
 constexpr int tap_k(int p, int a) { return p ? 2 * a : 2 * a + 1; }
 constexpr int tap_d(int p, int a) { return (p + 1 - tap_k(p, a)) / 2; }
 constexpr int tap_widx(int cls, int t) { return tap_k(cls >> 1, t / nk(cls & 1)) * 5 + tap_k(cls & 1, t % nk(cls & 1)); }
-constexpr int tap_aoff(int cls, int t) {  // LDS byte offset of the tap's source pixel relative to the lane's base
-  return ((tap_d(cls >> 1, t / nk(cls & 1)) + 1) * HWT + tap_d(cls & 1, t % nk(cls & 1)) + 1) * PITCH;
+constexpr int tap_aoff(int cls, int t, int hwp) {  // LDS byte offset of the tap's source pixel relative to the lane's base
+  return ((tap_d(cls >> 1, t / nk(cls & 1)) + 1) * hwp + tap_d(cls & 1, t % nk(cls & 1)) + 1) * PITCH;
 }
-template <int CLS, bool STATS, bool FUSE>
+template <int CLS, bool STATS, bool FUSE, bool PAIR>
 __device__ __forceinline__ void up4_run(const U4Params& p, char* smem, int lb, int G) {
+  constexpr int HWP = U4L<PAIR>::HWP, NPIECE = U4L<PAIR>::NPIECE, PPT = U4L<PAIR>::PPT;
   constexpr int F = ntaps_of(CLS) * KS;            // fragments per slice (16 | 24 | 36)
   constexpr int RING = F % 8 == 0 ? 8 : 12;
   double* sred = reinterpret_cast<double*>(smem + SRED_OFF);
@@ -79,16 +90,24 @@ __device__ __forceinline__ void up4_run(const U4Params& p, char* smem, int lb, i
     const int q = tid + u * 256;
     pl[u] = -1; pyx[u] = 0;
     if (q < NPIECE) {
-      const int px = q >> 3, pc = q & 7, hy = px / HWT, hx = px - hy * HWT;
-      pl[u] = px * PITCH + pc * 16;
-      pyx[u] = (pc << 16) | (hy << 8) | hx;
+      const int px = q >> 3, pc = q & 7;
+      if constexpr (PAIR) {   // pieces 0..799: sample n, 800..1599: sample n + 1 (bit 7 of the x byte)
+        const int sl = px >= PNPX, pp = px - PNPX * sl, hy = pp / PHW, hx = pp - hy * PHW;
+        pl[u] = (pp + PS1 * sl) * PITCH + pc * 16;
+        pyx[u] = (pc << 16) | (hy << 8) | (sl << 7) | hx;
+      } else {
+        const int hy = px / HWT, hx = px - hy * HWT;
+        pl[u] = px * PITCH + pc * 16;
+        pyx[u] = (pc << 16) | (hy << 8) | hx;
+      }
     }
   }
   int abase[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = i * 32 + pix32(r);
-    abase[i] = ((m >> 4) * HWT + (m & 15)) * PITCH + h * 16;
+    const int col = m & 15;
+    abase[i] = ((m >> 4) * HWP + (PAIR ? (col & 7) + PS1 * (col >> 3) : col)) * PITCH + h * 16;
   }
 
   unsigned long long wzero = 0;  // opaque zero, re-read per slice (see wfrag below)
@@ -98,6 +117,7 @@ __device__ __forceinline__ void up4_run(const U4Params& p, char* smem, int lb, i
     Item it;
     it.tn = rest % p.ntn;
     const int tm = rest / p.ntn;
+    if constexpr (PAIR) { it.n = 2 * tm; it.y0 = 0; it.x0 = 0; return it; }
     it.n = tm / p.tpi;
     const int tt = tm - it.n * p.tpi;
     it.y0 = (tt / p.tpi_x) * TH; it.x0 = (tt % p.tpi_x) * TW;
@@ -110,13 +130,14 @@ __device__ __forceinline__ void up4_run(const U4Params& p, char* smem, int lb, i
   const int sample_elems = p.Hs * p.Ws * p.Cs;
   auto issue = [&](const Item& it, int c0, u32x4 (&v)[PPT]) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.src + (long long)it.n * sample_elems), 0,
-                                                                        sample_elems * 2, 0x00027000);
+                                                                        (PAIR ? 2 : 1) * sample_elems * 2, 0x00027000);
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
       const int pq = pyx[u] + (int)wzero;  // (re-derived per slice: hoisted out of the slice loop these offsets spill)
-      const int sy = it.y0 - 1 + ((pq >> 8) & 255), sx = it.x0 - 1 + (pq & 255);
+      const int sy = it.y0 - 1 + ((pq >> 8) & 255), sx = it.x0 - 1 + (pq & (PAIR ? 127 : 255));
+      const int sl = PAIR ? (pq >> 7) & 1 : 0;
       const bool in = pl[u] >= 0 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
-      const unsigned off = in ? (unsigned)(((sy * p.Ws + sx) * p.Cs + c0 + (pq >> 16) * 8) * 2) : OOB;
+      const unsigned off = in ? (unsigned)((((sl * p.Hs + sy) * p.Ws + sx) * p.Cs + c0 + (pq >> 16) * 8) * 2) : OOB;
       v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
   };
@@ -169,14 +190,14 @@ __device__ __forceinline__ void up4_run(const U4Params& p, char* smem, int lb, i
     // order pinned as in conv_down3.hip: A fragments of step f+1 requested, 4 MFMAs of step f, ring slot refilled
     bf16x8 a[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + tap_aoff(CLS, 0));
+    for (int i = 0; i < 4; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + tap_aoff(CLS, 0, HWP));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int f = 0; f < F; ++f) {
       if (f + 1 < F) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          a[(f + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + tap_aoff(CLS, (f + 1 < F ? f + 1 : 0) / KS) + ((f + 1) % KS) * 32);
+          a[(f + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(hbuf + abase[i] + tap_aoff(CLS, (f + 1 < F ? f + 1 : 0) / KS, HWP) + ((f + 1) % KS) * 32);
       }
       const int slot = (f + OFF) % RING;
 #pragma unroll
@@ -224,13 +245,29 @@ __device__ __forceinline__ void up4_run(const U4Params& p, char* smem, int lb, i
         }
       }
       if constexpr (STATS) {
-        const double w1 = lg_wave_sum_d((double)s1v[0] + (double)s1v[1]), w2 = lg_wave_sum_d((double)s2v[0] + (double)s2v[1]);
-        if (lane == 0) { sred[(k & 1) * 16 + wid] = w1; sred[(k & 1) * 16 + 4 + wid] = w2; }
+        const double l1 = (double)s1v[0] + (double)s1v[1], l2 = (double)s2v[0] + (double)s2v[1];
+        if constexpr (PAIR) {  // a lane's 64 values all belong to ONE sample (its tile column never changes): masked sums
+          const bool sb = (pix32(r) & 8) != 0;
+          const double a1 = lg_wave_sum_d(sb ? 0.0 : l1), a2 = lg_wave_sum_d(sb ? 0.0 : l2);
+          const double b1 = lg_wave_sum_d(sb ? l1 : 0.0), b2 = lg_wave_sum_d(sb ? l2 : 0.0);
+          if (lane == 0) {
+            double* q = sred + (k & 1) * 16;
+            q[wid] = a1; q[4 + wid] = a2; q[8 + wid] = b1; q[12 + wid] = b2;
+          }
+        } else {
+          const double w1 = lg_wave_sum_d(l1), w2 = lg_wave_sum_d(l2);
+          if (lane == 0) { sred[(k & 1) * 16 + wid] = w1; sred[(k & 1) * 16 + 4 + wid] = w2; }
+        }
       }
-      // element offset of class pixel `row` (= 16 my + mx): output pixel (2 (y0 + my) + py, 2 (x0 + mx) + px)
+      // element offset of class pixel `row` (= 16 my + mx): output pixel (2 (y0 + my) + py, 2 (x0 + mx) + px); PAIR: columns
+      // 8..15 are sample n + 1
       constexpr int py = CLS >> 1, pxc = CLS & 1;
       const long long obase = ((long long)(cur.n * 2 * p.Hs + 2 * cur.y0 + py) * (2 * p.Ws) + 2 * cur.x0 + pxc) * p.N + cur.tn * 128;
-      auto pix_off = [&](int row) -> long long { return obase + ((long long)(2 * (row >> 4)) * (2 * p.Ws) + 2 * (row & 15)) * p.N; };
+      const long long sample_out = (long long)4 * p.Hs * p.Ws * p.N;
+      auto pix_off = [&](int row) -> long long {
+        if constexpr (PAIR) return obase + ((row >> 3) & 1) * sample_out + ((long long)(2 * (row >> 4)) * (2 * p.Ws) + 2 * (row & 7)) * p.N;
+        else return obase + ((long long)(2 * (row >> 4)) * (2 * p.Ws) + 2 * (row & 15)) * p.N;
+      };
       u32x4 zq[FUSE ? 8 : 1];
       (void)zq;
       if constexpr (FUSE) {  // requested now (the accumulators are dead): the loads land behind the barrier
@@ -249,7 +286,8 @@ __device__ __forceinline__ void up4_run(const U4Params& p, char* smem, int lb, i
         const u32x4 v = *reinterpret_cast<const u32x4*>(C + row * 256 + ((j ^ (row & 15)) << 4));
         *reinterpret_cast<u32x4*>(p.out + pix_off(row) + j * 8) = v;
         if constexpr (FUSE) {
-          const float* sp = p.nf.stats + (long long)cur.n * 8;
+          // PAIR: the tile column of a thread's pieces is fixed ((tid >> 4) & 15): waves 0, 1 sweep sample n, waves 2, 3 n + 1
+          const float* sp = p.nf.stats + (long long)(cur.n + (PAIR ? wid >> 1 : 0)) * 8;
           lg_nf_accum(v, zq[q8], sp[0], sp[4], sp[2], sp[3], p.nf.alpha, nf1, nf2);
         }
       }
@@ -257,24 +295,44 @@ __device__ __forceinline__ void up4_run(const U4Params& p, char* smem, int lb, i
         const double w1 = lg_wave_sum_d((double)nf1), w2 = lg_wave_sum_d((double)nf2);
         if (lane == 0) { sred[(k & 1) * 16 + wid] = w1; sred[(k & 1) * 16 + 4 + wid] = w2; }
       }
-      const int tin = (cur.y0 / TH) * p.tpi_x + cur.x0 / TW;
-      const long long prec = (long long)cur.n * p.nparts + (tin * 4 + CLS) * p.ntn + cur.tn;
+      const int tin = PAIR ? 0 : (cur.y0 / TH) * p.tpi_x + cur.x0 / TW;
+      const long long prec = (long long)cur.n * p.nparts + (tin * 4 + CLS) * p.ntn + cur.tn;   // PAIR: sample n + 1 is p.nparts further
       if constexpr (STATS) {
         if (tid == 0) {
-          constexpr double cnt = 128.0 * 128.0;
           const double* q = sred + (k & 1) * 16;
-          const double S1 = (q[0] + q[1]) + (q[2] + q[3]), S2 = (q[4] + q[5]) + (q[6] + q[7]);
-          const double md = S1 / cnt;
-          double* o = p.spart + prec * 3;
-          o[0] = cnt; o[1] = (double)shift + md; o[2] = S2 - cnt * md * md;
+          if constexpr (PAIR) {
+            constexpr double cnt = 64.0 * 128.0;
+#pragma unroll
+            for (int sm = 0; sm < 2; ++sm) {
+              const double S1 = (q[8 * sm] + q[8 * sm + 1]) + (q[8 * sm + 2] + q[8 * sm + 3]);
+              const double S2 = (q[8 * sm + 4] + q[8 * sm + 5]) + (q[8 * sm + 6] + q[8 * sm + 7]);
+              const double md = S1 / cnt;
+              double* o = p.spart + (prec + (long long)sm * p.nparts) * 3;
+              o[0] = cnt; o[1] = (double)shift + md; o[2] = S2 - cnt * md * md;
+            }
+          } else {
+            constexpr double cnt = 128.0 * 128.0;
+            const double S1 = (q[0] + q[1]) + (q[2] + q[3]), S2 = (q[4] + q[5]) + (q[6] + q[7]);
+            const double md = S1 / cnt;
+            double* o = p.spart + prec * 3;
+            o[0] = cnt; o[1] = (double)shift + md; o[2] = S2 - cnt * md * md;
+          }
         }
       }
       __syncthreads();  // C fully read before the buffer is staged again (sred alternates between two sets of slots)
       if constexpr (FUSE) {
         if (tid == 0) {
           const double* q = sred + (k & 1) * 16;
-          double* o = p.nf.part + prec * 2;
-          o[0] = (q[0] + q[1]) + (q[2] + q[3]); o[1] = (q[4] + q[5]) + (q[6] + q[7]);
+          if constexpr (PAIR) {
+#pragma unroll
+            for (int sm = 0; sm < 2; ++sm) {
+              double* o = p.nf.part + (prec + (long long)sm * p.nparts) * 2;
+              o[0] = q[2 * sm] + q[2 * sm + 1]; o[1] = q[4 + 2 * sm] + q[4 + 2 * sm + 1];
+            }
+          } else {
+            double* o = p.nf.part + prec * 2;
+            o[0] = (q[0] + q[1]) + (q[2] + q[3]); o[1] = (q[4] + q[5]) + (q[6] + q[7]);
+          }
         }
       }
 #pragma unroll
@@ -301,22 +359,23 @@ __device__ __forceinline__ void up4_run(const U4Params& p, char* smem, int lb, i
   }
 }
 
-template <bool STATS, bool FUSE>
+template <bool STATS, bool FUSE, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void conv_up4_kernel(const U4Params p) {
   static_assert(!(STATS && FUSE), "forward moments and backward sums are never needed together");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x;  // (uniform) class of this block: rank 0..3 = classes 3, 1, 2, 0
-  if (b < p.gend[0]) up4_run<3, STATS, FUSE>(p, smem, b, p.gend[0]);
-  else if (b < p.gend[1]) up4_run<1, STATS, FUSE>(p, smem, b - p.gend[0], p.gend[1] - p.gend[0]);
-  else if (b < p.gend[2]) up4_run<2, STATS, FUSE>(p, smem, b - p.gend[1], p.gend[2] - p.gend[1]);
-  else up4_run<0, STATS, FUSE>(p, smem, b - p.gend[2], p.gend[3] - p.gend[2]);
+  if (b < p.gend[0]) up4_run<3, STATS, FUSE, PAIR>(p, smem, b, p.gend[0]);
+  else if (b < p.gend[1]) up4_run<1, STATS, FUSE, PAIR>(p, smem, b - p.gend[0], p.gend[1] - p.gend[0]);
+  else if (b < p.gend[2]) up4_run<2, STATS, FUSE, PAIR>(p, smem, b - p.gend[1], p.gend[2] - p.gend[1]);
+  else up4_run<0, STATS, FUSE, PAIR>(p, smem, b - p.gend[2], p.gend[3] - p.gend[2]);
 }
 
 }  // namespace
 
 extern "C" int lg_conv_up4_supported(int B, int Hm, int Wm, int Cs, int N) {
-  return (!getenv("LG_NO_UP4") && B > 0 && Hm % TH == 0 && Wm % TW == 0 && Cs % KC == 0 && N % 128 == 0 &&
-          (long long)Hm * Wm * Cs * 2 < (1ll << 31)) ? 1 : 0;   // (one sample below the out-of-range offset of the halo loads)
+  const bool pair = Hm == 8 && Wm == 8 && B % 2 == 0 && !getenv("LG_NO_UP4_PAIR");   // 8 x 8 maps: a tile = two samples
+  return (!getenv("LG_NO_UP4") && B > 0 && ((Hm % TH == 0 && Wm % TW == 0) || pair) && Cs % KC == 0 && N % 128 == 0 &&
+          (long long)Hm * Wm * Cs * 2 * 2 < (1ll << 31)) ? 1 : 0;   // (two samples below the out-of-range offset of the halo loads)
 }
 
 // LG_OK: launched.  LG_ERR_UNSUPPORTED: the caller falls back to conv_halo.hip.  Hm, Wm: the SOURCE (small) map.
@@ -331,8 +390,11 @@ extern "C" int lg_conv_up4_nf_try(const void* src16, const void* wpack_up, const
   U4Params p{};
   p.src = (const __bf16*)src16; p.wp = (const char*)wpack_up; p.bias = bias; p.out = (__bf16*)out16;
   p.B = B; p.Hs = Hm; p.Ws = Wm; p.Cs = Cs; p.N = N; p.N32 = N / 32; p.KB = Cs / 16;
-  p.tpi_x = Wm / TW; p.tpi = p.tpi_x * (Hm / TH); p.ntn = N / 128;
-  const long long nper = (long long)B * p.tpi * p.ntn;
+  static int nopair = -1;
+  if (nopair < 0) nopair = getenv("LG_NO_UP4_PAIR") ? 1 : 0;
+  const bool pair = Hm == 8 && Wm == 8 && B % 2 == 0 && !nopair;
+  p.tpi_x = pair ? 1 : Wm / TW; p.tpi = pair ? 1 : p.tpi_x * (Hm / TH); p.ntn = N / 128;
+  const long long nper = (long long)(pair ? B / 2 : B) * p.tpi * p.ntn;
   if (nper <= 0 || 4 * nper >= (1ll << 30)) return LG_ERR_UNSUPPORTED;
   p.nper = (int)nper; p.nparts = p.tpi * 4 * p.ntn;
   const bool fuse = nf && nf->z && nf->stats && nf->part && nparts_out && (size_t)B * p.nparts * 2 * sizeof(double) <= nf_bytes;
@@ -353,6 +415,9 @@ extern "C" int lg_conv_up4_nf_try(const void* src16, const void* wpack_up, const
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_up4_kernel<true, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_up4_kernel<false, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_up4_kernel<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_up4_kernel<true, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_up4_kernel<false, false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_up4_kernel<false, true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   }
   // the grid is split between the classes in proportion to their tap counts (9 : 6 : 6 : 4), at most one block per item
   int grid = 0;
@@ -369,11 +434,15 @@ extern "C" int lg_conv_up4_nf_try(const void* src16, const void* wpack_up, const
     }
   }
   hipStream_t st = (hipStream_t)stream;
-  if (fuse) hipLaunchKernelGGL((conv_up4_kernel<false, true>), dim3(grid), dim3(256), LDS_BYTES, st, p);
+  if (pair) {
+    if (fuse) hipLaunchKernelGGL((conv_up4_kernel<false, true, true>), dim3(grid), dim3(256), LDS_BYTES, st, p);
+    else if (stats) hipLaunchKernelGGL((conv_up4_kernel<true, false, true>), dim3(grid), dim3(256), LDS_BYTES, st, p);
+    else hipLaunchKernelGGL((conv_up4_kernel<false, false, true>), dim3(grid), dim3(256), LDS_BYTES, st, p);
+  } else if (fuse) hipLaunchKernelGGL((conv_up4_kernel<false, true>), dim3(grid), dim3(256), LDS_BYTES, st, p);
   else if (stats) hipLaunchKernelGGL((conv_up4_kernel<true, false>), dim3(grid), dim3(256), LDS_BYTES, st, p);
   else hipLaunchKernelGGL((conv_up4_kernel<false, false>), dim3(grid), dim3(256), LDS_BYTES, st, p);
   LG_CHECK_LAUNCH("lg_conv_up4");
-  lg_note_kernel("conv_up4_kernel");
+  lg_note_kernel(pair ? "conv_up4_kernel<PAIR>" : "conv_up4_kernel");
   if (stats || fuse) *nparts_out = p.nparts;
   return LG_OK;
 }

@@ -77,6 +77,8 @@ def short(name):
         return f"patch_p16_kernel<{t(0)},{t(1)}" + (",nf>" if t(4) == "true" else ">")
     if base == "s1t_fwd_rows_kernel":
         return "s1t_fwd_rows_kernel<32,NORM>" if t(1) == "true" else "s1t_fwd_rows_kernel<32>"
-    if base in ("up_p16_kernel", "s1t_fwd_p16_kernel", "conv_up4_kernel"):
+    if base == "conv_up4_kernel":        # <STATS, FUSE, PAIR = false>
+        return "conv_up4_kernel<PAIR>" if t(2) == "true" else "conv_up4_kernel"
+    if base in ("up_p16_kernel", "s1t_fwd_p16_kernel"):
         return base
     return base + ("<" + ",".join(a) + ">" if a else "")

@@ -22,10 +22,12 @@ while time.time() < t_end:
     for _ in range(50):
         ops.convT_s2_fwd_stats(None, pack, bias, cb, dt, gm, bt, x16=x16, z16=True)
     torch.cuda.synchronize()
-st = buf.view(256, 8, 32).cpu().numpy()
+NW = 4 if (which != "t3" and not os.environ.get("LG_U3_T4_8W")) else 8
+NB = 256 * 8 // NW
+st = buf.view(NB, NW, 32).cpu().numpy()
 names = ["start", "class", "staged", "bar1", "rows", "(bar2+next start)"]
 for b in (0, 100):
-    for w in range(8):
+    for w in range(NW):
         row = st[b, w]
         n = int((row > 0).sum())
         d = [int(row[i] - row[i - 1]) for i in range(1, min(n, 16))]
@@ -33,9 +35,9 @@ for b in (0, 100):
 print("stamp order per item:", names)
 import numpy as np
 # per wave role: median cycles of each phase over all blocks and items (5 stamps per item)
-for w in range(8):
+for w in range(NW):
     ph = [[] for _ in range(5)]
-    for b in range(256):
+    for b in range(NB):
         row = st[b, w]; n = int((row > 0).sum())
         d = np.diff(row[:n])
         for i in range(len(d)):

@@ -20,6 +20,8 @@ CASES = [
     ("conv_up3_kernel<64, 32, true, false, 2>", "conv_up3_kernel<64,32>"),
     ("conv_up3_kernel<128, 64, false, true, 1>", "conv_up3_kernel<128,64>"),
     ("conv_up4_kernel<true, false>", "conv_up4_kernel"),
+    ("conv_up4_kernel<false, true, true>", "conv_up4_kernel<PAIR>"),
+    ("conv_up4_kernel<true, false, false>", "conv_up4_kernel"),
     ("wgrad_at_kernel<16, 8>", "wgrad_at_kernel<16,8>"),
     ("patch_p16_kernel<1, 32, true, false, true>", "patch_p16_kernel<1,32,nf>"),
     ("patch_p16_kernel<2, 64, true, true, false>", "patch_p16_kernel<2,64>"),

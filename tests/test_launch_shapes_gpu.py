@@ -293,7 +293,7 @@ def test_whole_step_forward_rows_at_batch_256():
 # (name, kind of the layer whose data gradient runs, cb, cs, small side s, sums fused at these shapes)
 #   conv  : dy16 [B,s,s,cs]   -> g [B,2s,2s,cb] = gradient of the encoder level below; UP contraction (conv_up3 / conv_up4 / conv_halo)
 #   convT : dy16 [B,2s,2s,cb] -> g [B,s,s,cs]   = gradient of the decoder level below; DOWN contraction (conv_down3)
-FUSED = [("enc.conv2", "conv", 64, 128, 32, True), ("enc.conv3", "conv", 128, 256, 16, True), ("enc.conv4", "conv", 256, 384, 8, False),
+FUSED = [("enc.conv2", "conv", 64, 128, 32, True), ("enc.conv3", "conv", 128, 256, 16, True), ("enc.conv4", "conv", 256, 384, 8, True),
          ("dec.conv2", "convT", 128, 256, 16, True), ("dec.conv3", "convT", 64, 128, 32, True), ("dec.conv4", "convT", 32, 64, 64, True)]
 
 

@@ -439,7 +439,8 @@ def test_bf16_path_down_kernels_small_shapes(ops, case):
     assert abs(outs[0][1] - outs[1][1]) < 1e-4 * (1 + abs(outs[1][1])) and abs(outs[0][2] - outs[1][2]) < 1e-4 * (1 + abs(outs[1][2]))
 
 
-@pytest.mark.parametrize("case", [(2, 8, 16, 64, 128), (1, 16, 16, 128, 256), (2, 8, 16, 128, 64), (2, 8, 16, 64, 32), (3, 16, 32, 64, 32), (5, 8, 16, 64, 32)])
+@pytest.mark.parametrize("case", [(2, 8, 16, 64, 128), (1, 16, 16, 128, 256), (2, 8, 16, 128, 64), (2, 8, 16, 64, 32), (3, 16, 32, 64, 32), (5, 8, 16, 64, 32),
+                                  (2, 8, 8, 64, 128), (4, 8, 8, 128, 256), (6, 8, 8, 64, 128), (3, 8, 8, 64, 128)])
 def test_bf16_path_up_kernels_small_shapes(ops, case):
     """The persistent UP kernels at small shapes through the bf16-activation entry points: conv_up4.hip (N % 128 == 0: blocks
     bound to one parity class) and conv_up3.hip ((128, 64) and (64, 32)): transposed-conv forward with fused moments, and the
@@ -457,7 +458,9 @@ def test_bf16_path_up_kernels_small_shapes(ops, case):
     ef = exp.reshape(B, -1)
     assert rel(st[:, 0].double() + st[:, 4].double(), ef.mean(1)) < 2e-5 and rel(st[:, 1], ef.std(1)) < 2e-5
     g16, np_ = ops.conv2d_s2_dgrad(None, pack, N, 1, dy16=x16, out_bf16=True, fuse=(z16, st, 0.3))
-    assert np_ is not None   # (round 3: the (64, 32) layer runs one tile per step on 4-wave workgroups and produces the sums too)
+    # (round 3: the (64, 32) layer runs one tile per step on 4-wave workgroups and produces the sums too; 8 x 8 maps with an even
+    #  batch = sample-PAIR tiles of conv_up4.hip, an odd batch falls back to conv_halo.hip, the only kernel without fused sums)
+    assert (np_ is not None) or (Hs == 8 and Ws == 8 and B % 2 == 1)
     assert rel(g16.float(), O.conv2d_transpose(_bf16_round(x), _bf16_round(w), np.zeros(N), 2)) < TOL[1]
     outs = []
     for parts in (np_, None):
