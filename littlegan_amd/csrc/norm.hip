@@ -337,7 +337,13 @@ __device__ __forceinline__ void store8_f32(float* p, long long i8, const f32x8& 
   *reinterpret_cast<f32x4*>(p + i8 * 8 + 4) = v.hi;
 }
 
-constexpr int EW8_UNR = 4;  // 16-B accesses in flight per thread and stream
+#ifndef LG_EW8_UNR
+#define LG_EW8_UNR 2   // r3 sweep (same box, B=256 maps): 2 beats 4 and 8 by 3 - 8 % on apply, apply + skip and the backward apply (more waves resident)
+#endif
+#ifndef LG_DB_UNR
+#define LG_DB_UNR 2
+#endif
+constexpr int EW8_UNR = LG_EW8_UNR;  // 16-B accesses in flight per thread and stream
 
 // y = leaky(a*((z - mu_hi) - mu_lo) + beta) [+ skip]  from the bf16 z;  SK: 0 none, 1 fp32 skip, 2 bf16 skip
 template <int SK>
@@ -435,7 +441,7 @@ __global__ __launch_bounds__(256) void bwd_apply16_kernel(const __bf16* __restri
                                                           float* __restrict__ dx, __bf16* __restrict__ dx16, long long L8,
                                                           long long total8, int pre_leaky, int post_leaky, float alpha,
                                                           float* __restrict__ colpart, int C8) {
-  constexpr int UNR = DB ? 2 : EW8_UNR;  // DB: the extra loads of a trip sit gridDim.x*256 units apart (same channel octet)
+  constexpr int UNR = DB ? LG_DB_UNR : EW8_UNR;  // DB: the extra loads of a trip sit gridDim.x*256 units apart (same channel octet)
   const unsigned tot = (unsigned)total8, l8 = (unsigned)L8;
   const unsigned ustep = DB ? gridDim.x * blockDim.x : 256u;                  // distance between a thread's units of one trip
   const unsigned stride = DB ? gridDim.x * blockDim.x * UNR : gridDim.x * blockDim.x * UNR;
