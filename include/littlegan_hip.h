@@ -144,6 +144,12 @@ int lg_instnorm_leaky_stats_z16(const float* x, float* stats, const float* gamma
                                 size_t ws_bytes, int B, long long L, int pre_leaky, float alpha, void* x16_out, void* stream);
 int lg_instnorm_stats_finalize(const void* partials, int nparts, float* stats, const float* gamma, const float* beta,
                                int B, void* stream);
+/* lg_instnorm_stats_finalize + lg_instnorm_leaky_apply_z16 (pre_leaky = 0) in ONE launch: partials = the [B][nparts][3] moment
+ * records of a *_fwd_stats conv; stats [B][8] receives the finished records, bit-identical to the two-call form
+ * (instance.py:114-127 + model.py:24,50) */
+int lg_instnorm_leaky_apply_z16_p(const void* z16, const void* partials, int nparts, const float* gamma, const float* beta,
+                                  float* stats, const void* skip, int skip_is_bf16, float* y, void* y16, int B, long long L,
+                                  int post_leaky, float alpha, void* stream);
 /* y = [post_leaky](a*([pre_leaky](x) - mu) + beta) [+ skip] ; y16 (may be null): bf16 mirror of y, the MFMA operand
  * image the bf16 conv / wgrad kernels consume instead of re-reading and re-rounding the fp32 tensor; y may be
  * null when only the mirror is wanted (at least one of y, y16) */

@@ -59,6 +59,7 @@ SIGNATURES = {
     "lg_instnorm_leaky_bwd_db": (I, [P, P, P, I, P, P, P, P, P, I, P, Z, I, L, I, I, F, I, P]),
     "lg_last_kernel": (C.c_char_p, []),
     "lg_instnorm_leaky_apply_z16": (I, [P, P, P, I, P, P, I, L, I, I, F, P]),
+    "lg_instnorm_leaky_apply_z16_p": (I, [P, P, I, P, P, P, P, I, P, P, I, L, I, F, P]),
     "lg_instnorm_leaky_bwd_z16": (I, [P, P, P, I, P, P, P, P, P, I, P, Z, I, L, I, I, F, I, P]),
     "lg_instnorm_leaky_bwd_z16_p": (I, [P, P, P, I, P, P, P, P, P, I, P, I, P, Z, I, L, I, I, F, I, P]),
     "lg_conv2d_s2_dgrad_nf": (I, [P, P, P, I, I, I, I, I, P, P, F, P, Z, P, P]),

@@ -384,6 +384,76 @@ __global__ __launch_bounds__(256) void apply16_kernel(const __bf16* __restrict__
   }
 }
 
+// apply16 with the statistics FINALISED IN THE SAME LAUNCH: grid (blocks per sample, B); the first wave of every block merges the
+// sample's moment partials {count, mean, M2} exactly as stats_final_kernel does (same order, same fp64 arithmetic: the record is
+// bit-identical), block 0 of a sample writes the record for the later consumers (backward, fused conv epilogues).  One launch and
+// one kernel boundary less per normalised map (22 per C3 step); post-LeakyReLU form only (pre_leaky = 0).
+template <int SK>
+__global__ __launch_bounds__(256) void apply16p_kernel(const __bf16* __restrict__ x, const double* __restrict__ partial, int nchunk,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ stats, const void* __restrict__ skip,
+                                                       float* __restrict__ y, __bf16* __restrict__ y16, unsigned L8,
+                                                       int post_leaky, float alpha) {
+  __shared__ float sst[8];
+  const int n = blockIdx.y;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const double* p = partial + (long long)n * nchunk * 3;
+    double cnt = 0.0, sum = 0.0;
+    for (int i = lane; i < nchunk; i += 64) { cnt += p[i * 3]; sum += p[i * 3] * p[i * 3 + 1]; }
+    cnt = lg_wave_sum_d(cnt); sum = lg_wave_sum_d(sum);
+    const double mean = sum / cnt;
+    double m2 = 0.0;
+    for (int i = lane; i < nchunk; i += 64) {
+      const double d = p[i * 3 + 1] - mean;
+      m2 += p[i * 3 + 2] + p[i * 3] * d * d;
+    }
+    m2 = lg_wave_sum_d(m2);
+    if (lane == 0) {
+      const double sigma = sqrt(m2 / cnt);
+      const double a = (double)gamma[0] / (sigma + (double)LG_IN_EPS);
+      const float mu_hi = (float)mean;
+      sst[0] = mu_hi; sst[1] = (float)sigma; sst[2] = (float)a; sst[3] = beta[0]; sst[4] = (float)(mean - (double)mu_hi);
+      if (blockIdx.x == 0) {
+        float* o = stats + (long long)n * LG_NSTAT;
+        o[0] = mu_hi; o[1] = (float)sigma; o[2] = (float)a; o[3] = beta[0];
+        o[4] = (float)(mean - (double)mu_hi); o[5] = 0.f; o[6] = 0.f; o[7] = 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  const float mu = sst[0], a = sst[2], b = sst[3], mul = sst[4];
+  const long long base = (long long)n * L8;
+  const unsigned stride = gridDim.x * blockDim.x * EW8_UNR;
+  for (unsigned i0 = blockIdx.x * blockDim.x * EW8_UNR + threadIdx.x; i0 < L8; i0 += stride) {
+    f32x8 v[EW8_UNR], sk[EW8_UNR];
+#pragma unroll
+    for (int u = 0; u < EW8_UNR; ++u) {
+      const unsigned i = i0 + u * 256;
+      if (i < L8) {
+        v[u] = load8<true>(x, base + i);
+        if constexpr (SK == 1) sk[u] = load8<false>(skip, base + i);
+        if constexpr (SK == 2) sk[u] = load8<true>(skip, base + i);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < EW8_UNR; ++u) {
+      const unsigned i = i0 + u * 256;
+      if (i >= L8) break;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float t = k < 4 ? v[u].lo[k & 3] : v[u].hi[k & 3];
+        t = a * ((t - mu) - mul) + b;
+        if (post_leaky) t = lg_leaky(t, alpha);
+        if constexpr (SK != 0) t += k < 4 ? sk[u].lo[k & 3] : sk[u].hi[k & 3];
+        if (k < 4) v[u].lo[k & 3] = t; else v[u].hi[k & 3] = t;
+      }
+      if (y) store8_f32(y, base + i, v[u]);
+      if (y16) store8_bf16(y16, base + i, v[u]);
+    }
+  }
+}
+
 // partial[n][blk] = {sum dz, sum dz*c} from the bf16 z; G16: gradient stored as bf16
 template <bool G16>
 __global__ __launch_bounds__(256) void bwd_partial16_kernel(const __bf16* __restrict__ x, const void* __restrict__ g,
@@ -684,6 +754,32 @@ extern "C" int lg_instnorm_leaky_apply_z16(const void* z16, const float* stats, 
     hipLaunchKernelGGL(apply16_kernel<2>, dim3((int)nb), dim3(256), 0, st, x, stats, skip, y, (__bf16*)y16, L / 8, total8,
                        pre_leaky, post_leaky, alpha);
   LG_CHECK_LAUNCH("lg_instnorm_leaky_apply_z16");
+  return LG_OK;
+}
+
+// lg_instnorm_stats_finalize + lg_instnorm_leaky_apply_z16 in ONE launch (see apply16p_kernel): `partials` = the [B][nparts][3]
+// moment records a *_fwd_stats conv left behind; `stats` [B][8] receives the finished records (bit-identical to the two-call form)
+extern "C" int lg_instnorm_leaky_apply_z16_p(const void* z16, const void* partials, int nparts, const float* gamma, const float* beta,
+                                             float* stats, const void* skip, int skip_is_bf16, float* y, void* y16, int B,
+                                             long long L, int post_leaky, float alpha, void* stream) {
+  LG_CHECK_ARG(z16 && partials && gamma && beta && stats && (y || y16), "lg_instnorm_leaky_apply_z16_p: null pointer");
+  LG_CHECK_ARG(nparts > 0 && B > 0 && B <= 65535 && L > 0 && L % 8 == 0 && L / 8 < (1LL << 31),
+               "lg_instnorm_leaky_apply_z16_p: bad shape B=%d L=%lld nparts=%d", B, L, nparts);
+  const long long L8 = L / 8;
+  long long bps = (L8 + 256 * EW8_UNR * 4 - 1) / (256 * EW8_UNR * 4);   // ~4 trips per block: the merge is paid once per 32 KB of z
+  if (bps * B > 8192) bps = 8192 / B;
+  if (bps < 1) bps = 1;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)bps, (unsigned)B);
+  const __bf16* x = (const __bf16*)z16;
+  const double* pr = (const double*)partials;
+  if (!skip)
+    hipLaunchKernelGGL(apply16p_kernel<0>, grid, dim3(256), 0, st, x, pr, nparts, gamma, beta, stats, skip, y, (__bf16*)y16, (unsigned)L8, post_leaky, alpha);
+  else if (!skip_is_bf16)
+    hipLaunchKernelGGL(apply16p_kernel<1>, grid, dim3(256), 0, st, x, pr, nparts, gamma, beta, stats, skip, y, (__bf16*)y16, (unsigned)L8, post_leaky, alpha);
+  else
+    hipLaunchKernelGGL(apply16p_kernel<2>, grid, dim3(256), 0, st, x, pr, nparts, gamma, beta, stats, skip, y, (__bf16*)y16, (unsigned)L8, post_leaky, alpha);
+  LG_CHECK_LAUNCH("lg_instnorm_leaky_apply_z16_p");
   return LG_OK;
 }
 

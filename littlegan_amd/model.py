@@ -23,6 +23,10 @@ from . import ops
 from ._lib import DT_BF16, DT_F32
 
 
+import os as _os
+_DEFER = not _os.environ.get("LG_NO_DEFER")   # A/B switch: moments finished by the apply launch (default) or by their own kernel
+
+
 def _dtype_of(args) -> int:
     name = getattr(args, "mfma_dtype", "f32")
     if name not in ("f32", "bf16"):
@@ -136,7 +140,7 @@ class Encoder(_ConvStack):
         for i, (cb, cs) in enumerate(self.chans, 1):
             gm, bt = self._w[f"norm{i}.gamma"], self._w[f"norm{i}.beta"]
             z, st = ops.conv2d_s2_fwd_stats(x, packs[i - 1], self._w[f"conv{i}.bias"], cs, self.dtype, gm, bt, x16=x16,
-                                            z16=m16, alpha=a)
+                                            z16=m16, alpha=a, defer_stats=m16 and _DEFER)
             if st is None:  # kernel without the fused-moments epilogue (small maps, 3-channel input)
                 st = ops.instnorm_stats(z, gm, bt, 0, a)
             if m16:
@@ -145,7 +149,8 @@ class Encoder(_ConvStack):
                 # skip add) and inputs of shapes only the per-tap gather kernel covers
                 need32 = i == 4 or not ops.conv_halo_supported(0, self.dtype, z.shape[0], z.shape[1] // 2, z.shape[2] // 2, cs,
                                                                self.chans[i][1])
-                h = ops.instnorm_apply(z, st, None, 0, 1, a, out16=h16, want_f32=need32)
+                h = ops.instnorm_apply(z, st, None, 0, 1, a, out16=h16, want_f32=need32)   # (finishes deferred moments itself)
+                st = ops.stats_tensor(st)
                 m = h if i == 4 else h16
             else:
                 h16 = None
@@ -246,7 +251,7 @@ class Decoder(_ConvStack):
         for i, (cb, cs) in enumerate(self.chans, 1):
             gm, bt = self._w[f"norm{i}.gamma"], self._w[f"norm{i}.beta"]
             z, st = ops.convT_s2_fwd_stats(x, packs[i - 1], self._w[f"conv{i}.bias"], cb, self.dtype, gm, bt, x16=x16,
-                                           z16=m16, alpha=a)
+                                           z16=m16, alpha=a, defer_stats=m16 and _DEFER)
             if st is None:
                 st = ops.instnorm_stats(z, gm, bt, 0, a)
             skip = add[i] if i < 4 else None
@@ -260,6 +265,7 @@ class Decoder(_ConvStack):
                 drop32 = want16 = m16 and ops.n3_m16_supported(z.shape[1], z.shape[2], self.args.image_channel, cb,
                                                                self.dtype)
             if i == 4 and raw_last and m16 and z.dtype == torch.bfloat16:
+                st = ops.stats_tensor(st)   # no apply pass here: the stand-alone finalize
                 saved.append((x, z, st, x16))
                 x, x16 = None, None
                 break
@@ -272,6 +278,7 @@ class Decoder(_ConvStack):
                                        out16=h16[lo:hi] if h16 is not None else None, want_f32=not drop32)
             else:
                 h = ops.instnorm_apply(z, st, skip, 0, 1, a, out16=h16, want_f32=not drop32)
+            st = ops.stats_tensor(st)   # deferred moments: finished by the apply launch(es) above
             saved.append((x, z, st, x16))
             x, x16 = h, h16
         if ctx is not None:

@@ -388,6 +388,43 @@ def conv_halo_supported(mode, dtype, B, Hm, Wm, Cs, N):
 
 
 # ------------------------------------------------------------------ instance norm
+class Moments:
+    """UNFINISHED InstanceNormalization moments of a conv output (bf16 activation path): the [B][nparts][3] partial records
+    {count, mean, M2} the conv epilogue left in the shared 'statpart' workspace, and the [B, NSTAT] tensor the finished
+    statistics go to.  The next norm call on this stream consumes them: instnorm_apply finishes them inside its own launch
+    (lg_instnorm_leaky_apply_z16_p: one launch and one kernel boundary less per normalised map); any other use goes through
+    stats_tensor(), which runs the stand-alone finalize.  Valid until the next conv with fused moments is enqueued."""
+
+    def __init__(self, ws, nparts, gamma, beta, B):
+        self.ws, self.nparts, self.gamma, self.beta, self.B = ws, int(nparts), gamma, beta, int(B)
+        self.stats = torch.empty(B, NSTAT, dtype=torch.float32, device=ws.device)
+        self.covered = 0   # rows whose records have been finished
+
+    def __getitem__(self, rows):
+        lo, hi, step = rows.indices(self.B)
+        if step != 1:
+            raise ValueError("Moments: contiguous row ranges only")
+        return _MomentRows(self, lo, hi)
+
+
+class _MomentRows:
+    def __init__(self, m, lo, hi):
+        self.m, self.lo, self.hi = m, lo, hi
+
+
+def stats_tensor(st):
+    """[B, NSTAT] statistics tensor of `st` (a tensor already, or Moments: finished here if no apply has done it)."""
+    if isinstance(st, _MomentRows):
+        return stats_tensor(st.m)[st.lo:st.hi]
+    if not isinstance(st, Moments):
+        return st
+    if st.covered < st.B:
+        check(_lib.load().lg_instnorm_stats_finalize(_p(st.ws), st.nparts, _p(st.stats), _p(st.gamma), _p(st.beta), st.B, _stream()),
+              "lg_instnorm_stats_finalize")
+        st.covered = st.B
+    return st.stats
+
+
 def instnorm_stats(x, gamma, beta, pre_leaky, alpha, stats=None, x16_out=None):
     """x16_out (optional bf16 tensor like x): also receives bf16(x) in the same pass."""
     B = x.shape[0]
@@ -423,6 +460,16 @@ def instnorm_apply(x, stats, skip, pre_leaky, post_leaky, alpha, out=None, out16
             raise ValueError("instnorm_apply: a bf16 input needs a multiple of 8 elements per sample")
     else:
         _chk(x, name="x")
+    pend = None   # unfinished moments (Moments / a row range of them): finished inside the apply launch where the kernel exists
+    if isinstance(stats, (Moments, _MomentRows)):
+        mrows = stats if isinstance(stats, _MomentRows) else _MomentRows(stats, 0, stats.B)
+        if mrows.hi - mrows.lo != B:
+            raise ValueError("instnorm_apply: moments cover a different number of samples")
+        if x_is16 and not pre_leaky and mrows.m.covered < mrows.m.B:
+            pend = mrows
+            stats = mrows.m.stats[mrows.lo:mrows.hi]
+        else:
+            stats = stats_tensor(stats)
     _chk(stats, (B, NSTAT), "stats")
     skip16 = skip is not None and skip.dtype == torch.bfloat16
     if skip is not None:
@@ -444,7 +491,14 @@ def instnorm_apply(x, stats, skip, pre_leaky, post_leaky, alpha, out=None, out16
         _chk(out, x.shape, "out")
     if out16 is not None:
         _chk16(out16, x, "out16")
-    if x_is16:
+    if pend is not None:
+        m = pend.m
+        part = m.ws.data_ptr() + pend.lo * m.nparts * 3 * 8
+        check(_lib.load().lg_instnorm_leaky_apply_z16_p(_p(x), part, m.nparts, _p(m.gamma), _p(m.beta), _p(stats), _p(skip), int(skip16),
+                                                        _p(out), _p(out16), B, Ln, int(post_leaky), float(alpha), _stream()),
+              "lg_instnorm_leaky_apply_z16_p")
+        m.covered += B
+    elif x_is16:
         check(_lib.load().lg_instnorm_leaky_apply_z16(_p(x), _p(stats), _p(skip), int(skip16), _p(out), _p(out16), B, Ln,
                                                       int(pre_leaky), int(post_leaky), float(alpha), _stream()),
               "lg_instnorm_leaky_apply_z16")
@@ -623,7 +677,7 @@ def adam_advance(state, b1, b2):
 
 
 # ------------------------------------------------------------------ conv forward with fused InstanceNorm moments
-def _fwd_stats(fn_name, x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, tag, flops, up):
+def _fwd_stats(fn_name, x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, tag, flops, up, defer=False):
     """Runs the conv (`out` fp32, or bf16 = the bf16 activation path); if its kernel produced per-block moment partials,
     finishes them into the stats record.  Returns stats [B, NSTAT] or None (caller then runs instnorm_stats)."""
     import ctypes
@@ -639,6 +693,8 @@ def _fwd_stats(fn_name, x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma
     _pe(e0, tag, flops)
     if nparts.value <= 0:
         return None
+    if defer:   # the consumer (instnorm_apply) finishes the records in its own launch
+        return Moments(ws, nparts.value, gamma, beta, B)
     stats = torch.empty(B, NSTAT, dtype=torch.float32, device=out.device)
     check(lib.lg_instnorm_stats_finalize(_p(ws), nparts.value, _p(stats), _p(gamma), _p(beta), B, _stream()),
           "lg_instnorm_stats_finalize")
@@ -648,7 +704,7 @@ def _fwd_stats(fn_name, x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma
 _FUSED_OK = {}
 
 
-def _fwd_stats_z16(fn_name, x, x16, pack, bias, shape, B, Hs, Ws, cb, cs, dtype, gamma, beta, tag, flops, up, alpha):
+def _fwd_stats_z16(fn_name, x, x16, pack, bias, shape, B, Hs, Ws, cb, cs, dtype, gamma, beta, tag, flops, up, alpha, defer=False):
     """bf16 activation path: z leaves the conv as bf16.  Where the conv kernel fuses the moments (from its fp32
     accumulators) that is the only copy ever written; otherwise the conv writes fp32 once, the statistics pass reads it
     and emits the bf16 copy in the same sweep, and the fp32 tensor is dropped.  Either way:
@@ -659,7 +715,7 @@ def _fwd_stats_z16(fn_name, x, x16, pack, bias, shape, B, Hs, Ws, cb, cs, dtype,
         _FUSED_OK[key] = bool(_lib.load().lg_conv_fwd_stats_fused(*key))
     if _FUSED_OK[key]:
         z16 = torch.empty(shape, dtype=torch.bfloat16, device=dev)
-        st = _fwd_stats(fn_name, x, x16, pack, bias, z16, B, Hs, Ws, cb, cs, dtype, gamma, beta, tag, flops, up)
+        st = _fwd_stats(fn_name, x, x16, pack, bias, z16, B, Hs, Ws, cb, cs, dtype, gamma, beta, tag, flops, up, defer=defer)
         if st is None:
             raise _lib.LittleGanHipError(f"{fn_name}: lg_conv_fwd_stats_fused promised fused moments for {key}, none came")
         return z16, st
@@ -672,9 +728,11 @@ def _fwd_stats_z16(fn_name, x, x16, pack, bias, shape, B, Hs, Ws, cb, cs, dtype,
     return z16, st
 
 
-def conv2d_s2_fwd_stats(x, pack, bias, cs, dtype, gamma, beta, x16=None, z16=False, alpha=0.3):
+def conv2d_s2_fwd_stats(x, pack, bias, cs, dtype, gamma, beta, x16=None, z16=False, alpha=0.3, defer_stats=False):
     """conv2d_s2_fwd + the InstanceNormalization statistics of its output -> (z, stats or None).
-    z16=True (bf16 dtype): z is returned as a bf16 tensor and stats is never None (see _fwd_stats_z16)."""
+    z16=True (bf16 dtype): z is returned as a bf16 tensor and stats is never None (see _fwd_stats_z16).
+    defer_stats (with z16): where the conv fuses the moments, `stats` comes back as an unfinished ops.Moments for the next
+    instnorm_apply to finish in its own launch (ops.stats_tensor() for any other use)."""
     B, H, W, cb = (x if x is not None else x16).shape  # x may be None when the bf16 mirror feeds the halo kernel
     if x is not None:
         _chk(x, name="x")
@@ -684,14 +742,14 @@ def conv2d_s2_fwd_stats(x, pack, bias, cs, dtype, gamma, beta, x16=None, z16=Fal
     tag, fl = "conv_igemm_patch" if cb == 3 else "conv_igemm_down", 50.0 * B * (H // 2) * (W // 2) * cb * cs
     if z16:
         return _fwd_stats_z16("lg_conv2d_s2_fwd_stats", x, x16, pack, bias, (B, H // 2, W // 2, cs), B, H // 2, W // 2, cb, cs,
-                              dtype, gamma, beta, tag, fl, False, alpha)
+                              dtype, gamma, beta, tag, fl, False, alpha, defer=defer_stats)
     out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.float32, device=bias.device)
     st = _fwd_stats("lg_conv2d_s2_fwd_stats", x, x16, pack, bias, out, B, H // 2, W // 2, cb, cs, dtype, gamma, beta, tag, fl,
                     up=False)
     return out, st
 
 
-def convT_s2_fwd_stats(x, pack, bias, cb, dtype, gamma, beta, x16=None, z16=False, alpha=0.3):
+def convT_s2_fwd_stats(x, pack, bias, cb, dtype, gamma, beta, x16=None, z16=False, alpha=0.3, defer_stats=False):
     B, Hs, Ws, cs = (x if x is not None else x16).shape
     if x is not None:
         _chk(x, name="x")
@@ -699,7 +757,7 @@ def convT_s2_fwd_stats(x, pack, bias, cb, dtype, gamma, beta, x16=None, z16=Fals
     fl = 50.0 * B * Hs * Ws * cb * cs
     if z16:
         return _fwd_stats_z16("lg_convT_s2_fwd_stats", x, x16, pack, bias, (B, 2 * Hs, 2 * Ws, cb), B, Hs, Ws, cb, cs, dtype,
-                              gamma, beta, "conv_igemm_up", fl, True, alpha)
+                              gamma, beta, "conv_igemm_up", fl, True, alpha, defer=defer_stats)
     out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.float32, device=bias.device)
     st = _fwd_stats("lg_convT_s2_fwd_stats", x, x16, pack, bias, out, B, Hs, Ws, cb, cs, dtype, gamma, beta, "conv_igemm_up", fl,
                     up=True)

@@ -26,7 +26,33 @@ RECORDED = ["conv_pack", "conv2d_s2_fwd_stats", "convT_s2_fwd_stats", "conv2d_s2
             "dense_fwd", "dense_wgrad", "heads_fwd", "heads_dgrad", "heads_wgrad"]
 
 
+class _LazyStats:
+    """deferred InstanceNorm moments (ops.Moments / a row range): their statistics tensor exists once the consuming apply has
+    run, so it is read when the call is CHECKED, after the recorded step"""
+
+    def __init__(self, m, lo, hi):
+        self.m, self.lo, self.hi = m, lo, hi
+
+    def resolve(self):
+        return self.m.stats[self.lo:self.hi].detach().to("cpu", copy=True)
+
+
+def _resolve(v):
+    if isinstance(v, _LazyStats):
+        return v.resolve()
+    if isinstance(v, (list, tuple)):
+        return type(v)(_resolve(u) for u in v)
+    if isinstance(v, dict):
+        return {k: _resolve(u) for k, u in v.items()}
+    return v
+
+
 def _snap(v):
+    from littlegan_amd import ops
+    if isinstance(v, ops.Moments):
+        return _LazyStats(v, 0, v.B)
+    if isinstance(v, ops._MomentRows):
+        return _LazyStats(v.m, v.lo, v.hi)
     if torch.is_tensor(v):
         return v.detach().to("cpu", copy=True)
     if isinstance(v, (list, tuple)):
@@ -150,7 +176,8 @@ def _kernel_affine_f32(x, st, pre_leaky, alpha):
 
 def check_call(rec, packs, stats=None):
     """Recomputes one recorded call with the oracle; raises AssertionError on a mismatch.  Returns a short tag."""
-    n, a, k, pa, pk, ret = rec["name"], rec["args"], rec["kwargs"], rec["post_args"], rec["post_kwargs"], rec["ret"]
+    n, a, k, pa, pk, ret = (rec["name"], _resolve(rec["args"]), _resolve(rec["kwargs"]), _resolve(rec["post_args"]),
+                            _resolve(rec["post_kwargs"]), _resolve(rec["ret"]))
     if n == "conv_pack":
         return "pack"
     if n in ("conv2d_s2_fwd_stats", "convT_s2_fwd_stats"):

@@ -574,3 +574,30 @@ def test_dense_dgrad(ops, B, K, N):
     dy, w = r32(rng, B, N), r32(rng, K, N, scale=0.1)
     dx = ops.dense_dgrad(dev(dy), dev(w))
     assert rel(dx, dy @ w.T) < 3e-5
+
+
+@pytest.mark.parametrize("case", [(4, 8, 16, 64, 128, False), (3, 16, 16, 64, 128, True), (2, 8, 16, 128, 64, True), (6, 8, 8, 64, 128, False)])
+def test_deferred_moments_finished_by_the_apply_launch(ops, case):
+    """lg_instnorm_leaky_apply_z16_p (finalize + apply in one launch; with a bf16 skip over two row ranges as the Adjuster's
+    decoder calls it) against the two-call form on the same conv output: statistics records and activated maps bit-identical."""
+    B, Hs, Ws, Cs, N, with_skip = case
+    rng = np.random.default_rng(zlib_crc(case) + 13)
+    x, w, b = r32(rng, B, Hs, Ws, Cs), r32(rng, 5, 5, N, Cs, scale=0.1), r32(rng, N, scale=0.2)
+    gm, bt = dev(np.array([1.2], dtype=np.float32)), dev(np.array([-0.1], dtype=np.float32))
+    x16 = dev(x).to(torch.bfloat16)
+    pack = ops.conv_pack(dev(w), N, Cs, 1)
+    z_a, st_a = ops.convT_s2_fwd_stats(None, pack, dev(b), N, 1, gm, bt, x16=x16, z16=True)
+    skip = dev(r32(rng, *z_a.shape)).to(torch.bfloat16) if with_skip else None
+    h_a = torch.empty_like(z_a)
+    ops.instnorm_apply(z_a, st_a, skip, 0, 1, 0.3, out16=h_a, want_f32=False)
+    z_b, mom = ops.convT_s2_fwd_stats(None, pack, dev(b), N, 1, gm, bt, x16=x16, z16=True, defer_stats=True)
+    assert isinstance(mom, ops.Moments) and torch.equal(z_a, z_b)
+    h_b = torch.empty_like(z_b)
+    b1 = B // 2
+    for lo, hi in ((0, b1), (b1, B)):
+        ops.instnorm_apply(z_b[lo:hi], mom[lo:hi], None if skip is None else skip[lo:hi], 0, 1, 0.3, out16=h_b[lo:hi], want_f32=False)
+    assert mom.covered == B
+    assert torch.equal(ops.stats_tensor(mom), st_a) and torch.equal(h_a, h_b)
+    # moments nobody applied: the stand-alone finalize
+    _, mom2 = ops.convT_s2_fwd_stats(None, pack, dev(b), N, 1, gm, bt, x16=x16, z16=True, defer_stats=True)
+    assert torch.equal(ops.stats_tensor(mom2), st_a)
