@@ -10,6 +10,8 @@
 // alternative (15 real columns (ky,co) + a per-lane select / cross-lane shift-sum) costs 3x the VALU issue slots, which
 // is what bounded the first version of this kernel.  Per row segment: 1.25 KB from L2/HBM (fetched once, 16 B per lane,
 // coalesced, two rows ahead), 6.25 KB of LDS traffic, 25 MFMAs (400 issue cycles), ~50 other instructions.
+// (Round 3, measured and dropped: the 25 B fragments in LDS instead of 100 VGPRs — 152 VGPRs, three blocks per CU instead of two,
+//  but 30 instead of 5 ds_read_b128 per 25 MFMAs make the LDS array the bound: 97 -> 128 us at B = 256.)
 // NORM: the input is the raw bf16 conv output z of the last decoder level and h = bf16(leaky(a*((z-mu)-mu_lo)+beta)) is
 // formed while staging (same arithmetic, same rounding as apply16_kernel in norm.hip) — the stand-alone apply pass and the
 // h16 tensor of the 128x128x32 map disappear.
