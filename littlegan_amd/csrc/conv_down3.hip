@@ -161,17 +161,23 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   // sat out the HBM latency of the halo it had just requested — 1600 of a slice's 5100 cycles for a lone wave, r3 census.)
   constexpr unsigned OOB = 0x80000000u;   // >= num_records for every supported shape (checked on the host)
   const int sample_elems = p.Hs * p.Ws * p.Cs;
-  auto issue = [&](const Item& it, int c0, u32x4 (&v)[PPT]) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__bf16*>(p.src + (long long)it.n * sample_elems), 0, (PAIR ? 2 : 1) * sample_elems * 2, 0x00027000);
+  // The piece offsets of an item are formed ONCE (set_item: ~90 VALU operations per thread) and every slice adds its channel offset:
+  // the slice boundary — where this wave issues no MFMA — is what a lone wave per SIMD pays in full (r3 census: 60 % of the pipe).
+  unsigned hoff[PPT];
+  auto set_item = [&](const Item& it) {
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
       const int sy = 2 * it.y0 - 1 + (pyx[u] >> 8), sx = 2 * it.x0 - 1 + (pyx[u] & (PAIR ? 127 : 255));
       const int sl = PAIR ? (pyx[u] >> 7) & 1 : 0;   // PAIR: second sample of the tile
       const bool ok = pl[u] >= 0 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
-      const unsigned off = ok ? (unsigned)((((sl * p.Hs + sy) * p.Ws + sx) * p.Cs + c0 + half8) * 2) : OOB;
-      v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+      hoff[u] = ok ? (unsigned)((((sl * p.Hs + sy) * p.Ws + sx) * p.Cs + half8) * 2) : OOB;   // (+ 2 c0 < 2^31 keeps OOB out of range)
     }
+  };
+  auto issue = [&](const Item& it, int c0, u32x4 (&v)[PPT]) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(p.src + (long long)it.n * sample_elems), 0, (PAIR ? 2 : 1) * sample_elems * 2, 0x00027000);
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hoff[u] + (unsigned)(c0 * 2), 0, 0));
   };
   auto commit = [&](char* buf, const u32x4 (&v)[PPT]) {
 #pragma unroll
@@ -218,6 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
 
   // ---- prologue: slice 0 of the first item ---------------------------------------------------------------------------
   Item cur = decode(0);
+  set_item(cur);
   issue(cur, 0, hv);
 #pragma unroll
   for (int t = 0; t < RING; ++t) bf[t] = wfrag(wbase(cur.tn, 0), t);
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
     const bool last_c = c + 1 == nchunk;
     Item nxt = cur;
     int c2 = c + 1;
-    if (last_c) { c2 = 0; if (more) nxt = decode(k + 1); }
+    if (last_c) { c2 = 0; if (more) { nxt = decode(k + 1); set_item(nxt); } }
     if (!more) c2 = c;  // final step: re-request the current slice (valid addresses, results unused) -> no branches below
     if constexpr (!(DBG & 4)) issue(nxt, c2 * KC, hv);
     const char* hbuf = smem + (s & 1) * HB;
