@@ -256,6 +256,9 @@ __global__ __launch_bounds__(256) void n3_wgrad16_kernel(const float* __restrict
   const int colbase = 16 * (g & 1) + 4 * lp;
 
   // the NEXT tile's operands are requested (global -> registers) before this tile's MFMAs and written to LDS behind them
+  // (round 3: TWO tiles ahead in two named register sets + branch-free buffer loads for the halo — the waves are parked at
+  //  s_waitcnt / barriers 51 - 67 % of their cycles — costs 256 / 208 VGPRs and the resident blocks that hide the rest: conv1 weight
+  //  gradient 83 -> 102 us, final 177 -> 290 us at B = 256.  Dropped.)
   constexpr int NPB = TH * TW * (Cs / 8) / 256;          // 16-B pieces of the wide operand per thread (2 | 4)
   constexpr int NPA = (20 * 36 * 3 + 255) / 256;         // halo floats per thread, s = 2 (the larger halo): 9
   u32x4 rb[NPB];
