@@ -18,12 +18,29 @@
 //   * the product is formed transposed (channels on accumulator rows, pixels on lanes) and leaves the registers through a
 //     WHOLE-OUTPUT-TILE staging area in LDS (16 x 32 output pixels x N channels): the four classes interleave there and
 //     the tile reaches HBM as contiguous rows of 32 pixels x N channels, 16 B per lane;
-//   * the InstanceNormalization moments of the tile come out of the same registers (one pass about a shift).
+//   * the InstanceNormalization moments of the tile come out of the same registers (one pass about a shift);
+//   * (round 3, forward forms) the staged tile's rows do not get a phase of their own: they leave INSIDE the next tile's MFMA
+//     stream, one ds_read_b128 + one buffer store per second fragment (see DEFERRED ROW SWEEP below).  Measured A/B on one box
+//     (LG_U3_NO_DEFER=1 variant): convT3 forward 113.4 -> 111.3 us, conv2 data gradient 124 -> 120.5 us, convT4 forward within noise
+//     (172-178 both ways): the row phase was the small part of the non-MFMA share (staging + the two barriers stay).
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 #include "lg_common.h"
 
+#ifndef LG_U3_PIECE_MODE
+#define LG_U3_PIECE_MODE 2
+#endif
+#ifndef LG_U3_NO_DEFER
+#define LG_U3_NO_DEFER 0
+#endif
+
 namespace {
+
+template <int... I, class Fn>
+__device__ __forceinline__ void lg_static_for_(std::integer_sequence<int, I...>, Fn&& fn) { (fn(std::integral_constant<int, I>{}), ...); }
+template <int N, class Fn>
+__device__ __forceinline__ void lg_static_for(Fn&& fn) { lg_static_for_(std::make_integer_sequence<int, N>{}, fn); }
 
 constexpr int TH = 8, TW = 16, HHT = TH + 2, HWT = TW + 2, NPX = HHT * HWT;  // 10 x 18 = 180 halo pixels
 constexpr int RING = 8;
@@ -201,6 +218,40 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
   commit(hv);
   __syncthreads();
 
+  // ---- DEFERRED ROW SWEEP (forward forms, !FUSE): the staged output tile of step s leaves for HBM INSIDE the MFMA stream of step
+  // s + 1 — per thread 8 pieces, one ds_read_b128 and one buffer store each, spread over the first fragments of the class loop —
+  // instead of in a phase of its own between two barriers (r3 stamps: staging / row stores / barriers are 36 % (N = 64) to 49 %
+  // (N = 32) of a step and nothing overlapped them).  Order per step: class loop (+ rows of the previous tile) | next halo requested
+  // | BARRIER (halo and staging area free) | stage | halo commit | BARRIER | moments of this tile.  The stores go through a buffer
+  // descriptor over the whole output: a tile that does not exist (step 0's "previous" tile, the odd tail) gets an out-of-range
+  // offset and its stores are dropped — no branch in the loop.
+  constexpr bool DEFER = !FUSE && !LG_U3_NO_DEFER;   // (LG_U3_NO_DEFER=1: the round-2 order, rows in a phase of their own — A/B builds)
+  constexpr int PPO_ = C::CROW / 16, TOT_ = C::NT * C::OPX * PPO_, NPC = TOT_ / NTH;   // pieces per thread and step (8)
+  // Piece q8 of thread tid is output pixel o = tid / PPO + q8 * (NTH / PPO) of tile (q8 * (NTH / PPO)) / OPX, 16-byte column tid % PPO:
+  // ONE LDS address and ONE global offset per thread (the swizzle term does not depend on q8), everything else is an immediate or
+  // a scalar — the tile's byte offset and the piece's row offset ride in the store's scalar offset.
+  constexpr int OPQ = NTH / PPO_;   // pixels between a thread's consecutive pieces
+  static_assert(C::OPX % OPQ == 0 && OPQ % 32 == 0 && (OPQ / 2) % PPO_ == 0, "piece map");
+  unsigned pbyte[C::NT];   // previous step's tiles: byte offset of their first output pixel
+  unsigned pnrec[C::NT];   // ... and the descriptor size: the output's, or 0 (no such tile: step 0, the odd tail) — stores dropped
+#pragma unroll
+  for (int t = 0; t < C::NT; ++t) { pbyte[t] = 0; pnrec[t] = 0; }
+  u32x4 rv;
+  const unsigned out_bytes = (unsigned)((long long)p.B * 4 * p.Hs * p.Ws * N * 2);   // < 0xffffff00 (host check)
+  const int po = tid / PPO_, pj = tid - po * PPO_;
+  const int plds = C::C_OFF + po * C::CROW + (((pj ^ (po >> 1)) & (PPO_ - 1)) << 4);
+  const unsigned pgl = (unsigned)((((po >> 5) * (2 * p.Ws) + (po & 31)) * N + pj * 8) * 2);
+  const unsigned prow = (unsigned)(2 * p.Ws * N * 2);   // bytes per output row
+  auto piece_lds = [&](int q8) {   // q8 is a compile-time constant at every call
+    const int t = (q8 * OPQ) / C::OPX, oq = (q8 * OPQ) % C::OPX;
+    return *reinterpret_cast<const u32x4*>(smem + plds + t * C::CB + oq * C::CROW);
+  };
+  auto piece_store = [&](int q8, const u32x4 v) {
+    const int t = (q8 * OPQ) / C::OPX, oq = (q8 * OPQ) % C::OPX;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)pnrec[t], 0x00027000);
+    __builtin_amdgcn_raw_buffer_store_b128(v, ors, pgl, (int)(pbyte[t] + (unsigned)(oq >> 5) * prow), 0);
+  };
+
   // one class of one tile: F = taps * KB fragments, ring position OFF at entry (F % RING != 0 only for CS = 64, class 3)
   auto run_class = [&](auto cls_c, auto off_c, auto next_c) {
     constexpr int CLS = decltype(cls_c)::value, OFF = decltype(off_c)::value;
@@ -220,9 +271,11 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(smem + abase[i] + a_off(0));
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-      if (f + 1 < F) {
+    // (a compile-time loop: with the deferred row sweep's f-dependent pieces inside, "#pragma unroll" left the 72-fragment loop
+    //  rolled — ring slots through s_set_gpr_idx)
+    lg_static_for<F>([&](auto f_c) {
+      constexpr int f = decltype(f_c)::value;
+      if constexpr (f + 1 < F) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[(f + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(smem + abase[i] + a_off(f + 1 < F ? f + 1 : 0));
       }
@@ -233,8 +286,23 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[sl]), a[f & 1][i], acc[i], 0, 0, 0);
       if constexpr (LG_U3_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
       // the stream wraps: the same class every step — or (ROT) runs on into the first fragments of the wave's NEXT class
-      if (f + RING < F) bf[sl] = *reinterpret_cast<const u32x4*>(frag_ptr(cls_c, f + RING));
+      if constexpr (f + RING < F) bf[sl] = *reinterpret_cast<const u32x4*>(frag_ptr(cls_c, f + RING));
       else bf[sl] = *reinterpret_cast<const u32x4*>(frag_ptr(next_c, f + RING - F));
+      // deferred row sweep of the previous tile: piece q is read from the staging area at fragment 1 + q STEP and stored one STEP later
+      constexpr int STEP = F >= 2 * NPC + 2 ? 2 : 1;
+      static_assert(!DEFER || F >= NPC * STEP + 2, "class loop too short for the deferred row sweep");
+      constexpr bool RD = DEFER && f >= 1 && (f - 1) % STEP == 0 && (f - 1) / STEP < NPC;
+      constexpr bool ST = DEFER && f >= 1 + STEP && (f - 1 - STEP) % STEP == 0 && (f - 1 - STEP) / STEP < NPC;
+#if LG_U3_PIECE_MODE == 2
+      if constexpr (ST || RD) __builtin_amdgcn_sched_barrier(0);
+#endif
+#if LG_U3_PIECE_MODE != 0
+      if constexpr (ST) piece_store((f - 1 - STEP) / STEP, rv);   // one register: piece q leaves, piece q + 1 is read behind it
+      if constexpr (RD) rv = piece_lds((f - 1) / STEP);
+#endif
+#if LG_U3_PIECE_MODE == 2
+      if constexpr (ST || RD) __builtin_amdgcn_sched_barrier(0);
+#endif
       if constexpr (LG_U3_SCHED == 0) {
         __builtin_amdgcn_sched_barrier(0);
       } else {  // one MFMA, one LDS read in its shadow, ..., the ring refill behind the last MFMA (see conv_down3.hip)
@@ -243,9 +311,13 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+#if LG_U3_PIECE_MODE == 1
+        if constexpr (ST) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // the piece store (its data arrived a STEP ago)
+        if constexpr (RD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the piece read
+#endif
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
-    }
+    });
   };
 
 #ifdef LG_U3_STAMPS
@@ -285,6 +357,7 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
     //  every ring wait of the first fragments also waited for them.)  Last step: the current halo again — valid addresses, result
     // unused, no branch around the loads.
     issue(more ? s + 1 : s, hv);
+    if constexpr (DEFER) __syncthreads();  // every halo read of this step and every row read of the previous tile is done
     // ---- this wave's class into the output-tile staging area: acc[i][e] = channel (e&3) + 8*(e>>2) + 4*h of pixel m ----------
     {
       char* Cst = smem + C::C_OFF + tsel * C::CB;
@@ -343,10 +416,18 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
         zq[q8] = tl ? *reinterpret_cast<const u32x4*>(p.nf.z + goff) : u32x4{0u, 0u, 0u, 0u};
       }
     }
-    __syncthreads();  // every class of the tile(s) is staged, every halo read is done
+    if constexpr (!DEFER) __syncthreads();  // every class of the tile(s) is staged, every halo read is done
     U3_STAMP();  // barrier 1 passed
 
     if (more) commit(hv);
+    if constexpr (DEFER) {
+      __syncthreads();  // tile staged, next halo in place; its rows leave inside the next class loop (or below, after the last step)
+#pragma unroll
+      for (int t = 0; t < C::NT; ++t) {
+        pbyte[t] = (unsigned)((((long long)(tns[t] * 2 * p.Hs + 2 * ty0s[t]) * (2 * p.Ws) + 2 * tx0s[t]) * N) * 2);
+        pnrec[t] = tlive[t] ? out_bytes : 0u;
+      }
+    } else
     // ---- whole output rows out: 16 rows x (32 pixels x N channels) contiguous, 16 B per lane ------------------------------
     {
       float nf1 = 0.f, nf2 = 0.f;
@@ -418,7 +499,11 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
     (void)live;
     U3_STAMP();  // rows out
     if constexpr (C::ROT) cls = rot_class(wid + s + 1);
-    __syncthreads();  // next halo complete, staging area free again
+    if constexpr (!DEFER) __syncthreads();  // next halo complete, staging area free again
+  }
+  if constexpr (DEFER) {  // the last tile's rows
+#pragma unroll
+    for (int q8 = 0; q8 < NPC; ++q8) piece_store(q8, piece_lds(q8));
   }
 }
 
@@ -467,6 +552,7 @@ extern "C" int lg_conv_up3_nf_try(const void* src16, const void* wpack_up, const
   if (nparts_out) *nparts_out = 0;
   if (!src16 || !wpack_up || !out16 || !lg_conv_up3_supported(B, Hm, Wm, Cs, N)) return LG_ERR_UNSUPPORTED;
   if ((long long)Hm * Wm * Cs * 2 * 2 >= (1ll << 31)) return LG_ERR_UNSUPPORTED;  // buffer descriptor: two samples below the OOB offset
+  if ((long long)B * 4 * Hm * Wm * N * 2 >= 0xffffff00ll) return LG_ERR_UNSUPPORTED;   // the row stores: one descriptor over the whole output
   U3Params p{};
   p.src = (const __bf16*)src16; p.wp = (const char*)wpack_up; p.bias = bias; p.out = (__bf16*)out16;
   p.B = B; p.Hs = Hm; p.Ws = Wm; p.tpi_x = Wm / TW; p.tpi = p.tpi_x * (Hm / TH);
