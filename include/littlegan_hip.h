@@ -64,6 +64,15 @@ int lg_conv_fwd_stats_fused(int up, int dtype, int B, int Hs, int Ws, int cb, in
 int lg_conv2d_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y, void* y16, int B,
                            int Hs, int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes, int* nparts,
                            void* stream);
+/* lg_conv2d_s2_fwd_stats fed with the RAW bf16 conv output z16 [B,2Hs,2Ws,cb] of the level below and its statistics records
+ * (zstats [B][8]): InstanceNormalization + LeakyReLU(alpha) (/root/reference/instance.py:105-128, model.py:22-24) are applied
+ * while the operand is staged — bit-identical to the stand-alone apply pass, whose tensor is never written.  For forward passes
+ * whose normalised maps have no other reader (/root/reference/eager_trainer.py:158-160: D on the Adjuster's output).  Result
+ * bf16 in y16, moment partials always fused.  LG_ERR_UNSUPPORTED unless ..._zn_supported. */
+int lg_conv2d_s2_fwd_stats_zn_supported(int B, int Hs, int Ws, int cb, int cs, int dtype);
+int lg_conv2d_s2_fwd_stats_zn(const void* z16, const float* zstats, float alpha, const void* pack, const float* bias, void* y16,
+                              int B, int Hs, int Ws, int cb, int cs, int dtype, void* spart, size_t spart_bytes, int* nparts,
+                              void* stream);
 /* *_m16: the activation operands may additionally be given as bf16 mirrors (x16 / dy16, same layout, may be null);
  * the bf16 MFMA kernels then read those instead of re-reading and re-rounding the fp32 tensors (bit-identical result) */
 /* dx16 (may be null): write the data gradient as bf16 there INSTEAD of fp32 to dx (dx may then be null) */

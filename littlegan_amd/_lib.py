@@ -41,6 +41,8 @@ SIGNATURES = {
     "lg_convT_s1_bwd_workspace_bytes": (Z, [I, I, I, I, I, I]),
     "lg_n3_m16_supported": (I, [I, I, I, I, I]),
     "lg_convT_s1_tanh_fwd_m16": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
+    "lg_conv2d_s2_fwd_stats_zn_supported": (I, [I, I, I, I, I, I]),
+    "lg_conv2d_s2_fwd_stats_zn": (I, [P, P, F, P, P, P, I, I, I, I, I, I, P, Z, P, P]),
     "lg_convT_s1_tanh_fwd_z16_supported": (I, [I, I, I, I, I]),
     "lg_convT_s1_tanh_fwd_z16": (I, [P, P, F, P, P, P, I, I, I, I, I, I, P]),
     "lg_convT_s1_tanh_bwd_m16": (I, [P, P, P, P, P, P, P, P, P, Z, I, I, I, I, I, I, I, P]),

@@ -117,6 +117,25 @@ extern "C" int lg_conv2d_s2_fwd_stats(const float* x, const void* x16, const voi
   return lg_conv_igemm_ex(MODE_DOWN, dtype, x, x16, pack, bias, y16 ? nullptr : y, y16, B, Hs, Ws, cb, cs, 0, 0, 0, spart,
                           spart_bytes, nparts, stream);
 }
+// The same forward pass fed with the RAW bf16 conv output z16 [B,2Hs,2Ws,cb] of the level below and its statistics records
+// (zstats [B][8]): x = bf16(LeakyReLU_alpha(InstanceNorm(z))) is formed while the kernel stages its operand (bit-identical to
+// lg_instnorm_leaky_apply_z16's output), the normalised map is never written.  For passes whose normalised maps have no other
+// reader (no weight gradient of this layer, no skip use): the discriminator run on the Adjuster's output.  The result is bf16
+// (y16) with fused moment partials, as lg_conv2d_s2_fwd_stats on the bf16 path.  LG_ERR_UNSUPPORTED unless ..._zn_supported.
+extern "C" int lg_conv_down3_zn_supported(int B, int Hm, int Wm, int Cs, int N);
+extern "C" int lg_conv_down3_zn_try(const void* z16, const float* zstats, float alpha, const void* wpack, const float* bias, void* out16,
+                                    int B, int Hm, int Wm, int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, void* stream);
+extern "C" int lg_conv2d_s2_fwd_stats_zn_supported(int B, int Hs, int Ws, int cb, int cs, int dtype) {
+  return (dtype == LG_DT_BF16 && cb != 3 && !getenv("LG_NO_HALO") && lg_conv_down3_zn_supported(B, Hs, Ws, cb, cs)) ? 1 : 0;
+}
+extern "C" int lg_conv2d_s2_fwd_stats_zn(const void* z16, const float* zstats, float alpha, const void* pack, const float* bias,
+                                         void* y16, int B, int Hs, int Ws, int cb, int cs, int dtype, void* spart,
+                                         size_t spart_bytes, int* nparts, void* stream) {
+  if (nparts) *nparts = 0;
+  LG_CHECK_ARG(z16 && zstats && pack && bias && y16 && spart && nparts, "lg_conv2d_s2_fwd_stats_zn: null pointer");
+  if (!lg_conv2d_s2_fwd_stats_zn_supported(B, Hs, Ws, cb, cs, dtype)) return LG_ERR_UNSUPPORTED;
+  return lg_conv_down3_zn_try(z16, zstats, alpha, pack, bias, y16, B, Hs, Ws, cb, cs, spart, spart_bytes, nparts, stream);
+}
 extern "C" int lg_convT_s2_fwd_stats(const float* x, const void* x16, const void* pack, const float* bias, float* y,
                                      void* y16, int B, int Hs, int Ws, int cb, int cs, int dtype, void* spart,
                                      size_t spart_bytes, int* nparts, void* stream) {

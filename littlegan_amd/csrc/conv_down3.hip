@@ -73,6 +73,8 @@ struct D3Params {
   int B, Hs, Ws, Cs, Hm, Wm, N, N32, KB;
   int tpi_x, tpi, ntn, nitems, nparts;
   LgNormFuse nf;       // FUSE instantiation: norm-backward sums of the produced gradient (lg_common.h)
+  const float* nstats; // NORM instantiation: src is the RAW output z of the layer below, these are its statistics records [B][8]
+  float nalpha;        //   ... and the operand is bf16(leaky(InstanceNorm(z))), formed while the halo is staged
   int stagger;         // start delay of the odd-slot block in ~1024-cycle units
   unsigned long long* stamps;  // diagnostic build only (LG_D3_STAMPS): [block][64] s_memtime stamps of wave 0
   int stamp_lite;              // only the block's first / last stamp (the per-phase stamps cost ~11 % and change the clock)
@@ -92,9 +94,19 @@ constexpr int toff_bytes(int t) {  // tap t = ky*5+kx: LDS byte offset of its so
 
 // NW = output channels per tile: 128 (each of the 4 waves owns 32 channels x all 128 pixels) or 64 (2 x 2 waves: 32 channels
 // x 64 pixels each — half the MFMAs per weight fragment, for the layers whose N is only a multiple of 64)
-template <bool STATS, bool FUSE = false, bool PAIR = false, int NW = 128>
+// NORM: the source is the raw bf16 conv output z of the layer below; InstanceNormalization + LeakyReLU (instance.py:105-128,
+// model.py:22-24) are applied to each halo piece between its buffer load and its LDS store — the same arithmetic and rounding as
+// apply16_kernel (norm.hip), so the operand image is bit-identical to the one a stand-alone apply pass would have written, and
+// that pass with its tensor disappears.  Pieces outside the image stay zero (TF SAME pads the NORMALISED map).  Forward passes
+// nothing differentiates the weights of (the discriminator run on the Adjuster's output, eager_trainer.py:158-160): there the
+// normalised maps have no other reader.  Measured at 2B = 512 (scripts/probe/zn_layers.py), apply pass + conv -> normalising conv:
+// conv2 (64 -> 128 channels, 64 x 64 map) 101 + 266 -> 272 us; conv3 (128 -> 256, 32 x 32) 46 + 197 -> 227 us.  The sample-PAIR
+// tiling of the 8 x 8 level was built too and LOSES (conv4: 27 + 189 -> 228 us: 16 slices per item, each re-normalising a halo the
+// three column tiles share) — it has no normalising form.
+template <bool STATS, bool FUSE = false, bool PAIR = false, int NW = 128, bool NORM = false>
 __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   static_assert(!(STATS && FUSE), "forward moments and backward sums are never needed together");
+  static_assert(!NORM || (STATS && NW == 128 && !PAIR), "the normalising form exists for the forward passes with fused moments, 8 x 16 tiles");
   static_assert(NW == 128 || (NW == 64 && !PAIR), "tile widths");
   constexpr int NWV = NW / 32, NI = NW / 32;          // waves along the channels; 32-pixel groups per wave (4 | 2)
   constexpr int PPR = NW / 8, NQ = 128 * PPR / 256;   // 16-B pieces per output pixel row; pieces per thread in the row sweep
@@ -164,7 +176,12 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   // The piece offsets of an item are formed ONCE (set_item: ~90 VALU operations per thread) and every slice adds its channel offset:
   // the slice boundary — where this wave issues no MFMA — is what a lone wave per SIMD pays in full (r3 census: 60 % of the pipe).
   unsigned hoff[PPT];
-  auto set_item = [&](const Item& it) {
+  float nmu0 = 0.f, nml0 = 0.f, nna0 = 0.f, nnb0 = 0.f;   // NORM: the item's sample
+  auto set_item = [&](const Item& it) __attribute__((always_inline)) {
+    if constexpr (NORM) {
+      const float* sp = p.nstats + (long long)it.n * 8;   // uniform: scalar loads
+      nmu0 = sp[0]; nna0 = sp[2]; nnb0 = sp[3]; nml0 = sp[4];
+    }
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
       const int sy = 2 * it.y0 - 1 + (pyx[u] >> 8), sx = 2 * it.x0 - 1 + (pyx[u] & (PAIR ? 127 : 255));
@@ -173,17 +190,23 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
       hoff[u] = ok ? (unsigned)((((sl * p.Hs + sy) * p.Ws + sx) * p.Cs + half8) * 2) : OOB;   // (+ 2 c0 < 2^31 keeps OOB out of range)
     }
   };
-  auto issue = [&](const Item& it, int c0, u32x4 (&v)[PPT]) {
+  auto issue = [&](const Item& it, int c0, u32x4 (&v)[PPT]) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16*>(p.src + (long long)it.n * sample_elems), 0, (PAIR ? 2 : 1) * sample_elems * 2, 0x00027000);
 #pragma unroll
     for (int u = 0; u < PPT; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hoff[u] + (unsigned)(c0 * 2), 0, 0));
   };
-  auto commit = [&](char* buf, const u32x4 (&v)[PPT]) {
+  auto commit = [&](char* buf, const u32x4 (&v)[PPT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < PPT; ++u)
       if (pl[u] >= 0) {
         u32x4 w = v[u];
+        if constexpr (NORM) {   // (hoff is the offset this very piece was requested with: commit follows the issue of the same slice)
+          const u32x4 hn = lg_norm8(w, nmu0, nml0, nna0, nnb0, p.nalpha);
+          const bool inside = hoff[u] != OOB;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) w[k] = inside ? hn[k] : 0u;
+        }
         if constexpr ((DBG & 16) != 0) {  // probe: the VALU cost of InstanceNorm + LeakyReLU applied while staging (norm.hip apply16 arithmetic)
           const float mu = p.nf.alpha, mul = 0.001f, na = 1.01f, nb = 0.02f, al = 0.3f;
 #pragma unroll
@@ -486,9 +509,29 @@ extern "C" int lg_conv_down3_try(const void* src16, const void* wpack, const flo
   return lg_conv_down3_nf_try(src16, wpack, bias, out16, B, Hm, Wm, Cs, N, spart, spart_bytes, nparts_out, nullptr, 0, stream);
 }
 // nf (optional; data-gradient use): also the norm-backward sums of the produced gradient ([B][*nparts_out][2] doubles)
+static int down3_launch(const void* src16, const void* wpack, const float* bias, void* out16, int B, int Hm, int Wm, int Cs, int N,
+                        void* spart, size_t spart_bytes, int* nparts_out, const LgNormFuse* nf, size_t nf_bytes,
+                        const float* nstats, float nalpha, void* stream);
+extern "C" int lg_conv_down3_supported(int B, int Hm, int Wm, int Cs, int N);
 extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const float* bias, void* out16, int B, int Hm, int Wm,
                                     int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, const LgNormFuse* nf,
                                     size_t nf_bytes, void* stream) {
+  return down3_launch(src16, wpack, bias, out16, B, Hm, Wm, Cs, N, spart, spart_bytes, nparts_out, nf, nf_bytes, nullptr, 0.f, stream);
+}
+// The forward pass fed with the RAW bf16 output z16 of the layer below and its statistics records (NORM form of the kernel):
+// moments of the produced map are always fused (spart must hold them) — LG_ERR_UNSUPPORTED otherwise and outside the kernel's tiling.
+extern "C" int lg_conv_down3_zn_try(const void* z16, const float* zstats, float alpha, const void* wpack, const float* bias, void* out16,
+                                    int B, int Hm, int Wm, int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, void* stream) {
+  if (nparts_out) *nparts_out = 0;
+  if (!zstats || !spart || !nparts_out || N % 128 != 0 || getenv("LG_NO_D3_NORM")) return LG_ERR_UNSUPPORTED;
+  return down3_launch(z16, wpack, bias, out16, B, Hm, Wm, Cs, N, spart, spart_bytes, nparts_out, nullptr, 0, zstats, alpha, stream);
+}
+extern "C" int lg_conv_down3_zn_supported(int B, int Hm, int Wm, int Cs, int N) {
+  return (!getenv("LG_NO_D3_NORM") && N % 128 == 0 && Hm % TH == 0 && Wm % TW == 0 && lg_conv_down3_supported(B, Hm, Wm, Cs, N)) ? 1 : 0;
+}
+static int down3_launch(const void* src16, const void* wpack, const float* bias, void* out16, int B, int Hm, int Wm, int Cs, int N,
+                        void* spart, size_t spart_bytes, int* nparts_out, const LgNormFuse* nf, size_t nf_bytes,
+                        const float* nstats, float nalpha, void* stream) {
   if (nparts_out) *nparts_out = 0;
   static int off = -1;
   if (off < 0) off = getenv("LG_NO_DOWN3") ? 1 : 0;  // A/B switch
@@ -514,6 +557,8 @@ extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const 
   if (!nf && spart && nparts_out && !stats) return LG_ERR_UNSUPPORTED;
   p.spart = stats ? (double*)spart : nullptr;
   if (fuse) p.nf = *nf;
+  if (nstats && (!stats || n64 || pair)) return LG_ERR_UNSUPPORTED;
+  p.nstats = nstats; p.nalpha = nalpha;
   static int nblk = 0;
   if (!nblk) {
     int dev = 0, cus = 256;
@@ -532,11 +577,14 @@ extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<true, false, false, 64>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, false, false, 64>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, true, false, 64>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<true, false, false, 128, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
   }
   const int grid = p.nitems < nblk ? p.nitems : nblk;
   hipStream_t st = (hipStream_t)stream;
   constexpr int LDS0 = D3L<false>::LDS_BYTES, LDS1 = D3L<true>::LDS_BYTES;
-  if (pair) {
+  if (nstats) {
+    hipLaunchKernelGGL((conv_down3_kernel<true, false, false, 128, true>), dim3(grid), dim3(256), LDS0, st, p);
+  } else if (pair) {
     if (fuse) hipLaunchKernelGGL((conv_down3_kernel<false, true, true>), dim3(grid), dim3(256), LDS1, st, p);
     else if (stats) hipLaunchKernelGGL((conv_down3_kernel<true, false, true>), dim3(grid), dim3(256), LDS1, st, p);
     else hipLaunchKernelGGL((conv_down3_kernel<false, false, true>), dim3(grid), dim3(256), LDS1, st, p);
@@ -548,7 +596,7 @@ extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const 
   else if (stats) hipLaunchKernelGGL(conv_down3_kernel<true>, dim3(grid), dim3(256), LDS0, st, p);
   else hipLaunchKernelGGL(conv_down3_kernel<false>, dim3(grid), dim3(256), LDS0, st, p);
   LG_CHECK_LAUNCH("lg_conv_down3");
-  lg_note_kernel(pair ? "conv_down3_kernel<PAIR>" : n64 ? "conv_down3_kernel<NW=64>" : "conv_down3_kernel<NW=128>");
+  lg_note_kernel(nstats ? "conv_down3_kernel<NW=128,NORM>" : pair ? "conv_down3_kernel<PAIR>" : n64 ? "conv_down3_kernel<NW=64>" : "conv_down3_kernel<NW=128>");
   if (stats || fuse) *nparts_out = p.nparts;
   return LG_OK;
 }

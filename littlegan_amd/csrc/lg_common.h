@@ -121,6 +121,20 @@ struct LgNormFuse {
   float alpha;
   int nparts;
 };
+// 8 bf16 z -> 8 bf16 h, exactly apply16_kernel (norm.hip): t = a*((z - mu) - mul) + b; leaky; RNE
+__device__ __forceinline__ u32x4 lg_norm8(const u32x4 z8, float mu, float mul, float a, float b, float alpha) {
+  u32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float t0 = __builtin_bit_cast(float, z8[k] << 16), t1 = __builtin_bit_cast(float, z8[k] & 0xffff0000u);
+    t0 = a * ((t0 - mu) - mul) + b; t1 = a * ((t1 - mu) - mul) + b;
+    t0 = lg_leaky(t0, alpha); t1 = lg_leaky(t1, alpha);
+    const __bf16 h0 = (__bf16)t0, h1 = (__bf16)t1;
+    o[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+  }
+  return o;
+}
+
 // 8 consecutive channels of one pixel: g8 / z8 = 16 B of bf16 each
 __device__ __forceinline__ void lg_nf_accum(const u32x4 g8, const u32x4 z8, float mu, float mul, float a, float b, float alpha,
                                             float& s1, float& s2) {

@@ -31,20 +31,6 @@ __device__ __forceinline__ bf16x8 cvt8w(const float* p) {
   return v;
 }
 
-// 8 bf16 z -> 8 bf16 h, exactly apply16_kernel (norm.hip): t = a*((z - mu) - mul) + b; leaky; RNE
-__device__ __forceinline__ u32x4 norm8(const u32x4 z8, float mu, float mul, float a, float b, float alpha) {
-  u32x4 o;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    float t0 = __builtin_bit_cast(float, z8[k] << 16), t1 = __builtin_bit_cast(float, z8[k] & 0xffff0000u);
-    t0 = a * ((t0 - mu) - mul) + b; t1 = a * ((t1 - mu) - mul) + b;
-    t0 = lg_leaky(t0, alpha); t1 = lg_leaky(t1, alpha);
-    const __bf16 h0 = (__bf16)t0, h1 = (__bf16)t1;
-    o[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-  }
-  return o;
-}
-
 template <int C, bool NORM>
 __global__ __launch_bounds__(256) void s1t_fwd_rows_kernel(const __bf16* __restrict__ x16, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y, int B, int H,
@@ -132,7 +118,7 @@ __global__ __launch_bounds__(256) void s1t_fwd_rows_kernel(const __bf16* __restr
     for (int k = 0; k < NL; ++k) {
       u32x4 v = rg[P][k];
       if constexpr (NORM) {
-        const u32x4 t = norm8(v, mu, mul, na, nb, ni.alpha);
+        const u32x4 t = lg_norm8(v, mu, mul, na, nb, ni.alpha);
         const bool ok = rok && goff[k] != OOB;  // padding stays zero (it is h that is zero-padded, not z)
         v = u32x4{ok ? t[0] : 0u, ok ? t[1] : 0u, ok ? t[2] : 0u, ok ? t[3] : 0u};
       }

@@ -135,7 +135,7 @@ class EagerTrainer:
             # Adjuster input = [img1 ; fake]: with the encoder maps of `fake` handed over, only img1 is encoded here
             adj_image = A([img1, adj_in_cond], ctx_a, enc_tails=tails)
             ctx_d2: dict = {}
-            p_a = D.forward_packed(adj_image, ctx_d2, keep_maps=False)
+            p_a = D.forward_packed(adj_image, ctx_d2, keep_maps=False, top_only=True)
             dz_a = torch.empty(2 * B, 1 + c, dtype=torch.float32, device=self.device)
             ops.bce_heads_loss(p_a, adj_t_cond, soft(1.0), 1.0, 1.0, self.losses["adj"], dz_a, False)
             g_adj = D.backward(ctx_d2, dz_a, need_wgrad=False, need_input_grad=True)

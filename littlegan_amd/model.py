@@ -24,6 +24,7 @@ from ._lib import DT_BF16, DT_F32
 
 
 import os as _os
+_ZN = not _os.environ.get("LG_NO_ZN")   # A/B switch: apply passes left to the consuming conv where no one else reads the map
 _DEFER = not _os.environ.get("LG_NO_DEFER")   # A/B switch: moments finished by the apply launch (default) or by their own kernel
 
 
@@ -121,7 +122,7 @@ class Encoder(_ConvStack):
     def _bias_dim(cb, cs):
         return cs
 
-    def __call__(self, inputs, ctx: Optional[dict] = None, tails=None, keep_maps: bool = True):
+    def __call__(self, inputs, ctx: Optional[dict] = None, tails=None, keep_maps: bool = True, top_only: bool = False):
         """Returns the 4 maps (model.py:27).  f32 path: fp32 tensors.  bf16 path: maps 1-3 are the bf16 mirrors the next
         conv reads anyway (they are also what the Adjuster's decoder adds as skips), map 4 (8x8, heads input) is fp32;
         the raw conv outputs z are kept in HBM as bf16 only (moments from the fp32 accumulators of the conv epilogue).
@@ -129,7 +130,11 @@ class Encoder(_ConvStack):
         tails (optional): the 4 maps this encoder already produced for MORE samples that follow `inputs` in the
         batch (same weights); each returned map is then the pair (own map, tail) instead of a recomputation or a
         concatenated copy (the Adjuster's input is [img1 ; fake] and D has just encoded `fake`).  Every op is
-        per-sample, so the result is identical."""
+        per-sample, so the result is identical.
+        top_only (bf16 path): the caller reads the LAST map only and no tape will ask this pass for a weight gradient (D on the
+        Adjuster's output, eager_trainer.py:158-160) — the normalised maps 1-3 then have one reader, the next conv, and where its
+        kernel can normalise while it stages (ops.conv2d_s2_fwd_stats_zn) they are never written: outs[i] is None there and the
+        context holds no x / x16 for the level above.  Bit-identical results."""
         x = inputs
         a = self.args.leaky_alpha
         packs = self.packs()
@@ -137,12 +142,28 @@ class Encoder(_ConvStack):
         saved = []
         m16 = self.dtype == DT_BF16  # bf16 MFMA path: keep a bf16 mirror of every conv input (the operand image)
         x16 = None
+        if top_only and (tails is not None or not m16):
+            top_only = False
+        raw = None   # (z, stats) of the level below when its apply pass was left out
         for i, (cb, cs) in enumerate(self.chans, 1):
             gm, bt = self._w[f"norm{i}.gamma"], self._w[f"norm{i}.beta"]
-            z, st = ops.conv2d_s2_fwd_stats(x, packs[i - 1], self._w[f"conv{i}.bias"], cs, self.dtype, gm, bt, x16=x16,
-                                            z16=m16, alpha=a, defer_stats=m16 and _DEFER)
+            # does the NEXT conv normalise this level's output itself?
+            Bn, Hn, Wn = (x if x is not None else x16 if x16 is not None else raw[0]).shape[:3]
+            skip_apply = (top_only and _ZN and i < 4 and
+                          ops.conv2d_s2_fwd_stats_zn_supported(Bn, Hn // 2, Wn // 2, cs, self.chans[i][1], self.dtype))
+            if raw is not None:
+                z, st = ops.conv2d_s2_fwd_stats_zn(raw[0], raw[1], a, packs[i - 1], self._w[f"conv{i}.bias"], cs, self.dtype, gm, bt)
+            else:
+                z, st = ops.conv2d_s2_fwd_stats(x, packs[i - 1], self._w[f"conv{i}.bias"], cs, self.dtype, gm, bt, x16=x16,
+                                                z16=m16, alpha=a, defer_stats=m16 and _DEFER and not skip_apply)
             if st is None:  # kernel without the fused-moments epilogue (small maps, 3-channel input)
                 st = ops.instnorm_stats(z, gm, bt, 0, a)
+            if skip_apply:
+                st = ops.stats_tensor(st)
+                outs.append(None)
+                saved.append((x, z, st, x16))
+                x, x16, raw = None, None, (z, st)
+                continue
             if m16:
                 h16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device)
                 # an fp32 copy only where something other than an MFMA operand load reads it: the top map (heads, first
@@ -157,7 +178,7 @@ class Encoder(_ConvStack):
                 h = m = ops.instnorm_apply(z, st, None, 0, 1, a)
             outs.append(m if tails is None else (m, tails[i - 1]))  # pair (own part, tail): no concatenated copy is made
             saved.append((x, z, st, x16))
-            x, x16 = h, h16
+            x, x16, raw = h, h16, None
         if ctx is not None:
             ctx["enc"] = saved
             ctx["enc_maps"] = outs
@@ -181,6 +202,9 @@ class Encoder(_ConvStack):
             need_wgrad = any_wgrad and i in levels
             cb, cs = self.chans[i - 1]
             x, z, st, x16 = ctx["enc"][i - 1]
+            if need_wgrad and x is None and x16 is None:
+                raise ValueError("Encoder.backward: this context was recorded with top_only=True (no normalised inputs kept): "
+                                 "it cannot give weight gradients")
             if rows is not None:
                 z, st = z[rows], st[rows]
                 x = x[rows] if x is not None else None
@@ -498,8 +522,9 @@ class Discriminator(_Module):
     def weights(self):
         return self.encoder.weights + [self._w[n] for n in self._names]
 
-    def forward_packed(self, image, ctx: Optional[dict] = None, keep_maps: bool = True):
-        outs = self.encoder(image, ctx, keep_maps=keep_maps)
+    def forward_packed(self, image, ctx: Optional[dict] = None, keep_maps: bool = True, top_only: bool = False):
+        """top_only: no weight gradient will be asked of this pass and only the heads read the encoder (see Encoder.__call__)."""
+        outs = self.encoder(image, ctx, keep_maps=keep_maps, top_only=top_only)
         x = outs[3].view(image.shape[0], -1)
         p = ops.heads_fwd(x, self._w["dense_pr.kernel"], self._w["dense_pr.bias"], self._w["dense_cond.kernel"],
                           self._w["dense_cond.bias"])

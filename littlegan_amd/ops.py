@@ -81,6 +81,11 @@ def pin_workspaces():
     _WS_PINNED = True
 
 
+def last_kernel() -> str:
+    """Name of the kernel the most recent conv-class C-ABI call launched on this thread (lg_last_kernel)."""
+    return _lib.load().lg_last_kernel().decode()
+
+
 def workspace(nbytes: int, device, tag="default") -> torch.Tensor:
     """Grow-only scratch buffer per (device, tag); kernels on one stream run in order so sharing is safe."""
     key = (str(device), tag)
@@ -747,6 +752,45 @@ def conv2d_s2_fwd_stats(x, pack, bias, cs, dtype, gamma, beta, x16=None, z16=Fal
     st = _fwd_stats("lg_conv2d_s2_fwd_stats", x, x16, pack, bias, out, B, H // 2, W // 2, cb, cs, dtype, gamma, beta, tag, fl,
                     up=False)
     return out, st
+
+
+_ZN_OK = {}
+
+
+def conv2d_s2_fwd_stats_zn_supported(B, H, W, cb, cs, dtype):
+    """H x W: the map the conv reads (as conv2d_s2_fwd_stats).  True where conv2d_s2_fwd_stats_zn runs."""
+    key = (B, H // 2, W // 2, cb, cs, dtype)
+    if key not in _ZN_OK:
+        _ZN_OK[key] = H % 2 == 0 and W % 2 == 0 and bool(_lib.load().lg_conv2d_s2_fwd_stats_zn_supported(*key))
+    return _ZN_OK[key]
+
+
+def conv2d_s2_fwd_stats_zn(zin16, zin_stats, alpha, pack, bias, cs, dtype, gamma, beta):
+    """conv2d_s2_fwd_stats (bf16 path) fed with the RAW bf16 output zin16 [B,H,W,cb] of the level below and its statistics
+    records: InstanceNorm + LeakyReLU(alpha) happen while the conv stages its operand, the normalised map is never written
+    (bit-identical to instnorm_apply + conv2d_s2_fwd_stats).  -> (z16 [B,H/2,W/2,cs] bf16, stats [B, NSTAT])."""
+    import ctypes
+    lib = _lib.load()
+    B, H, W, cb = zin16.shape
+    _chk16(zin16, zin16, "zin16")
+    _chk(zin_stats, (B, NSTAT), "zin_stats")
+    _chk(bias, (cs,), "bias")
+    if not conv2d_s2_fwd_stats_zn_supported(B, H, W, cb, cs, dtype):
+        raise ValueError(f"conv2d_s2_fwd_stats_zn: shape {tuple(zin16.shape)} -> {cs} is outside the normalising kernel's tiling")
+    Hs, Ws = H // 2, W // 2
+    ws = workspace(int(lib.lg_conv_stats_workspace_bytes(0, B, Hs, Ws, cs)), zin16.device, "statpart")
+    z16 = torch.empty(B, Hs, Ws, cs, dtype=torch.bfloat16, device=zin16.device)
+    nparts = ctypes.c_int(0)
+    e0 = _pb()
+    check(lib.lg_conv2d_s2_fwd_stats_zn(_p(zin16), _p(zin_stats), float(alpha), _p(pack), _p(bias), _p(z16), B, Hs, Ws, cb, cs, dtype,
+                                        _p(ws), ws.numel(), ctypes.addressof(nparts), _stream()), "lg_conv2d_s2_fwd_stats_zn")
+    _pe(e0, "conv_igemm_down", 50.0 * B * Hs * Ws * cb * cs)
+    if nparts.value <= 0:
+        raise _lib.LittleGanHipError("lg_conv2d_s2_fwd_stats_zn: no moment partials came back")
+    stats = torch.empty(B, NSTAT, dtype=torch.float32, device=zin16.device)
+    check(lib.lg_instnorm_stats_finalize(_p(ws), nparts.value, _p(stats), _p(gamma), _p(beta), B, _stream()),
+          "lg_instnorm_stats_finalize")
+    return z16, stats
 
 
 def convT_s2_fwd_stats(x, pack, bias, cb, dtype, gamma, beta, x16=None, z16=False, alpha=0.3, defer_stats=False):

@@ -405,6 +405,50 @@ def test_final_layer_normalises_while_staging(ops, case):
     assert rel(y, exp) < 3e-5
 
 
+@pytest.mark.parametrize("case", [(2, 8, 16, 32, 128), (3, 16, 16, 64, 128), (4, 8, 16, 64, 256), (2, 16, 16, 128, 384), (5, 16, 32, 32, 128),
+                                  (64, 32, 32, 64, 128)])
+def test_down_conv_normalises_while_staging(ops, case):
+    """lg_conv2d_s2_fwd_stats_zn (NORM form of conv_down3.hip): InstanceNorm + LeakyReLU applied to the raw bf16 conv output of
+    the level below while the stride-2 conv stages its halo == the stand-alone apply pass followed by the same conv, bit for bit
+    (result and moments); and against the oracle on the rounded operands.  8 x 16 tiles with one and several tiles per sample,
+    odd batch, several column tiles (N = 256, 384), a batch with more items than persistent blocks.  Samples get different
+    statistics (per-sample offsets and scales)."""
+    B, Hm, Wm, Cs, N = case
+    rng = np.random.default_rng(zlib_crc(case) + 5)
+    zin = r32(rng, B, 2 * Hm, 2 * Wm, Cs, scale=1.0)
+    zin = zin * (0.5 + rng.random((B, 1, 1, 1), dtype=np.float32) * 2.0) + rng.standard_normal((B, 1, 1, 1)).astype(np.float32)
+    w, b = r32(rng, 5, 5, Cs, N, scale=0.05), r32(rng, N, scale=0.1)
+    gm, bt = dev(np.array([0.9], dtype=np.float32)), dev(np.array([0.2], dtype=np.float32))
+    gm2, bt2 = dev(np.array([1.2], dtype=np.float32)), dev(np.array([-0.1], dtype=np.float32))
+    alpha = 0.3
+    zin16 = torch.empty(B, 2 * Hm, 2 * Wm, Cs, dtype=torch.bfloat16, device="cuda")
+    st_in = ops.instnorm_stats(dev(zin), gm, bt, 0, alpha, x16_out=zin16)
+    h16 = torch.empty_like(zin16)
+    ops.instnorm_apply(zin16, st_in, None, 0, 1, alpha, out16=h16, want_f32=False)
+    pack = ops.conv_pack(dev(w), Cs, N, 1)
+    assert ops.conv2d_s2_fwd_stats_zn_supported(B, 2 * Hm, 2 * Wm, Cs, N, 1)
+    z_ref, st_ref = ops.conv2d_s2_fwd_stats(None, pack, dev(b), N, 1, gm2, bt2, x16=h16, z16=True, alpha=alpha)
+    assert ops.last_kernel().startswith("conv_down3_kernel")
+    z, st = ops.conv2d_s2_fwd_stats_zn(zin16, st_in, alpha, pack, dev(b), N, 1, gm2, bt2)
+    assert "NORM" in ops.last_kernel()
+    assert torch.equal(z, z_ref) and torch.equal(st, ops.stats_tensor(st_ref))
+    if B <= 8:
+        exp = O.conv2d(h16.double().cpu().numpy(), _bf16_round(w), b, 2)
+        assert rel(z.float(), exp) < TOL[1]   # bf16 result
+        ef = exp.reshape(B, -1)
+        assert rel(st[:, 0].double() + st[:, 4].double(), ef.mean(1)) < 2e-5 and rel(st[:, 1], ef.std(1)) < 2e-5
+
+
+def test_down_conv_zn_declines_outside_its_tiling(ops):
+    assert not ops.conv2d_s2_fwd_stats_zn_supported(2, 16, 32, 32, 64, 1)    # 64-column tiles: no normalising form
+    assert not ops.conv2d_s2_fwd_stats_zn_supported(2, 12, 12, 32, 128, 1)   # map not tileable
+    assert not ops.conv2d_s2_fwd_stats_zn_supported(2, 16, 16, 32, 128, 1)   # 8 x 8 result: sample-pair tiles, no normalising form (measured: loses)
+    assert not ops.conv2d_s2_fwd_stats_zn_supported(2, 16, 32, 32, 128, 0)   # f32 path
+    with pytest.raises(ValueError):
+        ops.conv2d_s2_fwd_stats_zn(torch.zeros(2, 16, 32, 32, dtype=torch.bfloat16, device="cuda"), torch.zeros(2, 8, device="cuda"), 0.3,
+                                   None, torch.zeros(64, device="cuda"), 64, 1, None, None)
+
+
 @pytest.mark.parametrize("case", [(2, 8, 8, 32, 128), (4, 8, 8, 64, 256), (3, 8, 8, 32, 128), (1, 8, 16, 32, 64), (2, 16, 16, 32, 64),
                                   (1, 8, 16, 32, 128)])
 def test_bf16_path_down_kernels_small_shapes(ops, case):

@@ -366,3 +366,30 @@ def test_predict_matches_oracle(tmp_path, mfma):
     a_ref, _ = O.adjuster_fwd(cfg, W, image, cond)
     assert np.abs(adj_real.cpu().numpy() - a_ref).max() < tol["img"]
     assert adj_fake.shape == adj_real.shape
+
+
+@pytest.mark.parametrize("init_dim,B", [(8, 6), (8, 5), (16, 2)])
+def test_disc_pass_without_normalised_maps_is_bit_identical(init_dim, B):
+    """Discriminator.forward_packed(top_only=True) — the pass the step runs on the Adjuster's output (eager_trainer.py:158-160): the
+    apply passes of encoder levels 1-3 are left to the consuming conv (lg_conv2d_s2_fwd_stats_zn) where its kernel covers the shape.
+    Head probabilities and the image gradient of the following data-gradient chain are bit-identical to the pass that writes every
+    normalised map; the context of such a pass refuses weight gradients.  (The conv that produces the 8 x 8 level has no normalising
+    form — measured slower — so at 128 x 128 images the level-3 map is written; at 256 x 256 all three apply passes go.)"""
+    cfg = O.Cfg(init_dim=init_dim, cond_dim=40, batch_size=B)
+    tr = build(cfg, perturbed(cfg, 3), "bf16")
+    D = tr.discriminator
+    g = torch.Generator(device="cuda").manual_seed(5)
+    img = torch.tanh(torch.randn(B, 16 * init_dim, 16 * init_dim, 3, device="cuda", generator=g))
+    dz = torch.randn(B, 41, device="cuda", generator=g) * 0.1
+    ctx0, ctx1 = {}, {}
+    p0 = D.forward_packed(img, ctx0, keep_maps=False).clone()
+    p1 = D.forward_packed(img, ctx1, keep_maps=False, top_only=True).clone()
+    skipped = [m is None for m in ctx1["enc_maps"]]
+    assert skipped == [True, True, init_dim == 16, False], skipped
+    assert all(m is not None for m in ctx0["enc_maps"])
+    assert torch.equal(p0, p1)
+    g0 = D.backward(ctx0, dz, need_wgrad=False, need_input_grad=True).clone()
+    g1 = D.backward(ctx1, dz, need_wgrad=False, need_input_grad=True).clone()
+    assert torch.equal(g0, g1)
+    with pytest.raises(ValueError):
+        D.backward(ctx1, dz, need_wgrad=True, need_input_grad=False)
