@@ -341,7 +341,13 @@ class Decoder(_ConvStack):
                 zl, stl = ctx["dec"][i - 2][1], ctx["dec"][i - 2][2]  # the level the gradient belongs to
                 g_h, nfp = ops.convT_s2_dgrad(None, packs[i - 1], cs, self.dtype, dy16=dz16, out_bf16=True, fuse=(zl, stl, a))
             else:
-                g_h = ops.convT_s2_dgrad(dz, packs[i - 1], cs, self.dtype, dy16=dz16, out_bf16=(self.dtype == DT_BF16 and i > 1))
+                # bf16 path: every data gradient of the decoder leaves its conv as bf16 — also level 1's, which the dense + norm
+                # backward reads as fp32: the persistent bf16-output kernels (conv_down3.hip) then cover that level too (its
+                # fp32-output route was the last user of the round-1 halo kernel here, 150-200 us per call against ~100), and the
+                # widening cast of an 8 x 8 x 384 map is ~6 us
+                g_h = ops.convT_s2_dgrad(dz, packs[i - 1], cs, self.dtype, dy16=dz16, out_bf16=self.dtype == DT_BF16)
+                if i == 1 and g_h.dtype == torch.bfloat16:
+                    g_h = g_h.float()
         return g_h if need_input_grad else None
 
 

@@ -431,8 +431,7 @@ def decoder_bwd(cfg, Wd, caches, g_h, need_wgrad=True):
         dz, dg, dbe = instnorm_bwd(nc, g[0], dy)
         dx, dw, _ = conv2d_transpose_bwd(x, _q(cfg, k), _q(cfg, dz), 2)
         db = dz.sum(axis=(0, 1, 2))
-        if i > 0:
-            dx = _q(cfg, dx)  # bf16 between the levels; fp32 where it leaves the decoder (dense layer)
+        dx = _q(cfg, dx)  # (bf16 emulation) every data gradient of the decoder is stored as bf16, the one handed to the dense layer too
         _trace(f"dec{i + 1}.dz", dz)
         _trace(f"dec{i + 1}.dx", dx)
         if need_wgrad:

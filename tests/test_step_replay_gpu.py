@@ -36,8 +36,11 @@ def _replay(cfg, mfma, b, seed=7):
 @pytest.mark.parametrize("init_dim", [4, 8])
 def test_every_call_of_a_full_step_matches_the_oracle(mfma, init_dim):
     seen = _replay(O.Cfg(init_dim=init_dim, cond_dim=40, batch_size=2), mfma, 11)
-    # G fwd (4 convT) + Adjuster fwd (4 convT) ; D fwd on [real;fake], A's encoder on img1, D fwd on adj (3 x 4 conv)
-    assert seen["convT_s2_fwd_stats"] == 8 and seen["conv2d_s2_fwd_stats"] == 12
+    # G fwd (4 convT) + Adjuster fwd (4 convT) ; D fwd on [real;fake], A's encoder on img1, D fwd on adj (3 x 4 conv) — in the bf16
+    # path D on adj hands raw maps to the normalising conv where its tiling covers the level (64 x 64 images: level 2; 128 x 128: 2, 3)
+    zn = seen.get("conv2d_s2_fwd_stats_zn", 0)
+    assert zn == ((1 if init_dim == 4 else 2) if mfma == "bf16" else 0)
+    assert seen["convT_s2_fwd_stats"] == 8 and seen["conv2d_s2_fwd_stats"] + zn == 12
     # disc tape 4 + gen tape 4 + adj tape 4 encoder levels, G tape 4 + adj tape 4 decoder levels, 2 dense norms
     assert seen["instnorm_bwd"] == 22
     assert seen["conv2d_s2_wgrad"] == 4 and seen["convT_s2_wgrad"] == 4 and seen["convT_s1_tanh_bwd"] == 2
