@@ -22,6 +22,7 @@
 namespace {
 
 struct RowsNormIn { const float* stats; float alpha; };
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ bf16x8 cvt8w(const float* p) {
   const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
@@ -31,43 +32,70 @@ __device__ __forceinline__ bf16x8 cvt8w(const float* p) {
   return v;
 }
 
-template <int C, bool NORM>
-__global__ __launch_bounds__(256) void s1t_fwd_rows_kernel(const __bf16* __restrict__ x16, const float* __restrict__ w,
+// XJ (1 | 2): x positions per accumulator row.  XJ = 1 is the form described at the top.  XJ = 2 (W % 32 == 0) puts TWO neighbouring
+// output pixels of every co on the MFMA columns (column n = 3 j + co, j = 0 | 1): a wave then owns a strip of 32 columns, MFMA row m
+// is the pixel PAIR (2m, 2m + 1), and the kx shifts of both pixels fold into SIX A fragments t = 0..5 (staged pixel 2m + t) with
+// B_t[c][3 j + co] = W[ky][j + 4 - t][co][c] (zero where j + 4 - t is no tap): 30 MFMAs per 32 output pixels instead of 50, six
+// ds_read_b128 instead of ten, half the per-row bookkeeping — the round-2 form ran 25 MFMAs of 16 issue cycles per 16 pixels, as
+// long as the HBM time of the same pixels, and the two did not overlap (98 us at B = 256 against 45 us of bytes).
+// LDS layout of a staged row, XJ = 2: pixel PAIRS at a pitch of 2 * 64 + 16 bytes — lane r of a fragment read sits r pairs on, so the
+// 16 lanes of a ds_read_b128 group fall into 16 different 4-bank sets (pitch / 4 mod 64 = 36: an odd multiple of 4).  XJ = 1 keeps the
+// round-2 layout (64 B per pixel, 16-B pieces XOR-swizzled by the pixel quad): the padded form measured 130 us against 100 there.
+template <int C, bool NORM, int XJ>
+__global__ __launch_bounds__(256, XJ == 2 ? 2 : 1) void s1t_fwd_rows_kernel(const __bf16* __restrict__ x16, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y, int B, int H,
                                                            int W, int RB, const RowsNormIn ni) {
-  static_assert(C == 32, "one K = 32 MFMA step per tap; 25 B fragments of 4 registers stay resident");
-  constexpr int NPC = C / 8, NP = 20 * NPC, NL = (NP + 63) / 64, FSH = 2;
-  constexpr int ROWB = 20 * C * 2;                 // staged row
+  static_assert(C == 32, "one K = 32 MFMA step per fragment; the B fragments of 4 registers stay resident");
+  static_assert(XJ == 1 || XJ == 2, "x positions per accumulator row");
+  constexpr int SW = 16 * XJ, SP = SW + 4;          // output columns of a wave's strip; staged pixels of a row
+  constexpr int NT = XJ + 4;                        // A fragments (pixel shifts) per row
+  constexpr int NPC = C / 8, NP = SP * NPC, NL = (NP + 63) / 64;
+  constexpr int GP = XJ == 1 ? C * 2 : XJ * C * 2 + 16;   // pitch of a group of XJ staged pixels
+  constexpr int ROWB = (SP / XJ) * GP;              // staged row
+  auto poff = [](int p, int j) {                    // byte offset of 16-B piece j of staged pixel p
+    if constexpr (XJ == 1) return p * C * 2 + (((j ^ (p >> 2)) & (NPC - 1)) << 4);
+    else return (p / XJ) * GP + (p % XJ) * C * 2 + j * 16;
+  };
+  constexpr int NO = 48 * XJ, VW = XJ, NLN = NO / VW;   // output floats of a row segment; floats per storing lane; storing lanes (48)
   constexpr unsigned OOB = 0x40000000u;            // buffer offsets >= this are out of range for any image here (< 1 GiB)
   // per wave: the staged row, then 64 x 16 B of dump slots (lanes with nothing to stage write there: the steady-state loop
   // has NO branch — a branch makes the compiler wait for ALL outstanding loads at the join, i.e. one HBM latency per row)
   __shared__ __attribute__((aligned(16))) char srow[4][2 * ROWB + 64 * 16];  // two row buffers: row s+1 is staged under the MFMAs of row s
-  __shared__ __attribute__((aligned(16))) float sout[4][48 + 64];
+  __shared__ __attribute__((aligned(16))) float sout[4][NO + 64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
-  const int nsx = (W + 63) / 64, nry = (H + RB - 1) / RB;
+  const int nsx = (W + 4 * SW - 1) / (4 * SW), nry = (H + RB - 1) / RB;
   int bb = blockIdx.x;
   const int sx = bb % nsx; bb /= nsx;
   const int ry = bb % nry, n = bb / nry;
-  const int x0 = sx * 64 + wid * 16;
+  const int x0 = sx * 4 * SW + wid * SW;
   if (x0 >= W) return;  // no block barrier anywhere below
   const int ya = ry * RB, yb = min(ya + RB, H), cnt = yb - ya + 4;
   char* my = srow[wid];
   float* mo = sout[wid];
 
-  // B fragment (ky,kx): column nn = co (3..15 = padding), k = channel: lane l holds B[k = 8(l>>4) + j][col l&15]
-  bf16x8 bw[5][5];
+  // B fragment (ky, t): column nn = 3 j + co (3 XJ .. 15 = padding), k = channel: lane l holds B[k = 8(l>>4) + i][col l&15];
+  // its tap is kx = j + 4 - t
+  bf16x8 bw[5][NT];
+  {
+    const int j = r / 3, co = r - 3 * j;
 #pragma unroll
-  for (int ky = 0; ky < 5; ++ky)
+    for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
-    for (int kx = 0; kx < 5; ++kx)
-      bw[ky][kx] = r < 3 ? cvt8w(w + (long long)((ky * 5 + kx) * 3 + r) * C + g * 8) : __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
-  const float bl = bias[lane % 3];
+      for (int t = 0; t < NT; ++t) {
+        const int kx = j + 4 - t;
+        bw[ky][t] = (r < 3 * XJ && kx >= 0 && kx < 5) ? cvt8w(w + (long long)((ky * 5 + (kx < 0 ? 0 : kx > 4 ? 4 : kx)) * 3 + co) * C + g * 8)
+                                                      : __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+      }
+  }
+  float bl[VW];
+#pragma unroll
+  for (int k = 0; k < VW; ++k) bl[k] = bias[(lane * VW + k) % 3];
   float mu = 0.f, mul = 0.f, na = 1.f, nb = 0.f;
   if constexpr (NORM) {
     const float* sp = ni.stats + (long long)n * 8;
     mu = sp[0]; na = sp[2]; nb = sp[3]; mul = sp[4];
   }
-  // staging geometry: piece q = lane + 64k of the 20-pixel row -> pixel p, 16-B piece j.  The row is fetched with raw
+  // staging geometry: piece q = lane + 64k of the SP-pixel row -> pixel p, 16-B piece j.  The row is fetched with raw
   // buffer loads over this image (num_records = its bytes): pieces left / right of the image and rows above / below it
   // get an out-of-range offset and come back as zeros.
   unsigned goff[NL];
@@ -76,7 +104,7 @@ __global__ __launch_bounds__(256) void s1t_fwd_rows_kernel(const __bf16* __restr
   for (int k = 0; k < NL; ++k) {
     const int q = lane + 64 * k, p = q / NPC, j = q - p * NPC, xx = x0 - 2 + p;
     goff[k] = (q < NP && (unsigned)xx < (unsigned)W) ? (unsigned)(xx * C + j * 8) * 2u : OOB;
-    loff[k] = q < NP ? p * C * 2 + (((j ^ (p >> FSH)) & (NPC - 1)) << 4) : 2 * ROWB + lane * 16;
+    loff[k] = q < NP ? poff(p, j) : 2 * ROWB + lane * 16;
     lbuf[k] = q < NP ? ROWB : 0;
   }
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -92,24 +120,24 @@ __global__ __launch_bounds__(256) void s1t_fwd_rows_kernel(const __bf16* __restr
 #pragma unroll
     for (int k = 0; k < NL; ++k) dst[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[k] + ro, 0, 0);
   };
-  // A fragment of shift kx: lane (r, g) needs pixel p = r + 4 - kx, channels 8g .. 8g+7 (piece g)
-  int aoff[5];
+  // A fragment of shift t: lane (r, g) needs staged pixel XJ r + t (image column x0 - 2 + XJ r + t), channels 8g .. 8g+7 (piece g):
+  // XJ = 2: its pair is r + t / 2 — the lane's base plus a constant
+  int aoffs[NT];
 #pragma unroll
-  for (int kx = 0; kx < 5; ++kx) {
-    const int p = r + 4 - kx;
-    aoff[kx] = p * C * 2 + (((g ^ (p >> FSH)) & (NPC - 1)) << 4);
-  }
-  // output staging: lane (r < 3, g) drops row x = 4g + e at float (4g + e)*3 + r; other lanes into their dump slot
-  const int wofs = r < 3 ? (4 * g * 3 + r) : 48 + lane;
-  const int wstep = r < 3 ? 3 : 0;
-  const unsigned yofs = lane < 48 ? (unsigned)((x0 * 3 + lane) * 4) : OOB;
+  for (int t = 0; t < NT; ++t) aoffs[t] = poff(XJ * r + t, g);
+  auto aoff = [&](int t) { return aoffs[t]; };
+  // output staging: lane (column nn < 3 XJ, g) drops accumulator row m = 4g + e (pixels XJ m + j) at float m * 3 XJ + nn;
+  // other lanes into their dump slot
+  const int wofs = r < 3 * XJ ? (4 * g * 3 * XJ + r) : NO + lane;
+  const int wstep = r < 3 * XJ ? 3 * XJ : 0;
+  const unsigned yofs = lane < NLN ? (unsigned)((x0 * 3 + lane * VW) * 4) : OOB;
 
   // the five output rows in flight are five NAMED tiles handed to a step by reference in rotated order (an accumulator
   // ARRAY indexed by the step would become a runtime-indexed private array, i.e. scratch memory)
   f32x4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = T0, T2 = T0, T3 = T0, T4 = T0;
 
-  // row s: registers -> (norm) -> wave-private LDS buffer s & 1, then its five A fragments
-  bf16x8 af[2][5];
+  // row s: registers -> (norm) -> wave-private LDS buffer s & 1, then its A fragments
+  bf16x8 af[2][NT];
   auto stage = [&](auto p_c, int s) {
     constexpr int P = decltype(p_c)::value;
     const int yy = ya - 2 + s;
@@ -126,33 +154,44 @@ __global__ __launch_bounds__(256) void s1t_fwd_rows_kernel(const __bf16* __restr
     }
     fetch(s + 2, rg[P]);
 #pragma unroll
-    for (int kx = 0; kx < 5; ++kx) af[P][kx] = *reinterpret_cast<const bf16x8*>(my + P * ROWB + aoff[kx]);
+    for (int t = 0; t < NT; ++t) af[P][t] = *reinterpret_cast<const bf16x8*>(my + P * ROWB + aoff(t));
   };
   // input row s (yy = ya - 2 + s) adds to the output rows yy - 2 + ky: O0 (ky = 0) is completed by it, O4 (ky = 4) starts.
-  // Row s + 1 is staged and its fragments requested BEFORE the 25 MFMAs of row s, so the LDS round trip hides under them.
+  // Row s + 1 is staged and its fragments requested BEFORE the MFMAs of row s, so the LDS round trip hides under them.
   auto step = [&](auto p_c, int s, f32x4& O0, f32x4& O1, f32x4& O2, f32x4& O3, f32x4& O4) {
     constexpr int P = decltype(p_c)::value;
     stage(std::integral_constant<int, P ^ 1>{}, s + 1);
     O4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kx = 0; kx < 5; ++kx) {  // five independent accumulation chains
-      O0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P][kx], bw[0][kx], O0, 0, 0, 0);
-      O1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P][kx], bw[1][kx], O1, 0, 0, 0);
-      O2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P][kx], bw[2][kx], O2, 0, 0, 0);
-      O3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P][kx], bw[3][kx], O3, 0, 0, 0);
-      O4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P][kx], bw[4][kx], O4, 0, 0, 0);
+    for (int t = 0; t < NT; ++t) {  // five independent accumulation chains
+      O0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P][t], bw[0][t], O0, 0, 0, 0);
+      O1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P][t], bw[1][t], O1, 0, 0, 0);
+      O2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P][t], bw[2][t], O2, 0, 0, 0);
+      O3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P][t], bw[3][t], O3, 0, 0, 0);
+      O4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[P][t], bw[4][t], O4, 0, 0, 0);
     }
     // output row ya + s - 4 is complete (when 4 <= s < cnt; otherwise the store offset is out of range and dropped):
-    // C layout row (= x) 4g + e, column r (= co for r < 3)
+    // C layout row (= pixel group m) 4g + e, column r (= 3 j + co for r < 3 XJ)
 #pragma unroll
     for (int e = 0; e < 4; ++e) mo[wofs + e * wstep] = O0[e];
     {
       // tanh(v) = 1 - 2 / (1 + e^{2v}): |error| < 2e-7 absolute over the whole range (e^{2v} -> inf / 0 saturate to +-1)
-      const float v = mo[lane] + bl;
-      const float ex = __builtin_amdgcn_exp2f(v * 2.885390082f);
-      const float o = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + ex);
       const unsigned yo = sel(s >= 4 && s < cnt, (unsigned)((ya + s - 4) * W * 12), OOB);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), yrsrc, yofs + yo, 0, 0);
+      if constexpr (VW == 1) {
+        const float v = mo[lane] + bl[0];
+        const float ex = __builtin_amdgcn_exp2f(v * 2.885390082f);
+        const float o = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + ex);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), yrsrc, yofs + yo, 0, 0);
+      } else {
+        const f32x2 v2 = *reinterpret_cast<const f32x2*>(mo + 2 * lane);   // (lanes >= 48 read dump slots; their store is out of range)
+        u32x2 o2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float ex = __builtin_amdgcn_exp2f((v2[k] + bl[k]) * 2.885390082f);
+          o2[k] = __builtin_bit_cast(unsigned, 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + ex));
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(o2, yrsrc, yofs + yo, 0, 0);
+      }
     }
   };
 
@@ -188,11 +227,20 @@ extern "C" int lg_n3_s1t_fwd_rows_try(const void* x16, const float* stats, float
   if (off || !lg_n3_rows_supported(H, W, C) || !x16 || !w || !bias || !y) return LG_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int RB = H <= 64 ? H : 64;
-  const dim3 grid(B * ((W + 63) / 64) * ((H + RB - 1) / RB));
   const RowsNormIn ni{stats, alpha};
   const __bf16* x = (const __bf16*)x16;
-  if (stats) hipLaunchKernelGGL((s1t_fwd_rows_kernel<32, true>), grid, dim3(256), 0, st, x, w, bias, y, B, H, W, RB, ni);
-  else hipLaunchKernelGGL((s1t_fwd_rows_kernel<32, false>), grid, dim3(256), 0, st, x, w, bias, y, B, H, W, RB, ni);
+  static int no2 = -1;
+  if (no2 < 0) no2 = getenv("LG_ROWS_XJ1") ? 1 : 0;   // A/B switch: the one-pixel-per-row form everywhere
+  const bool xj2 = W % 32 == 0 && !no2;
+  const int sw = xj2 ? 32 : 16;
+  const dim3 grid(B * ((W + 4 * sw - 1) / (4 * sw)) * ((H + RB - 1) / RB));
+  if (xj2) {
+    if (stats) hipLaunchKernelGGL((s1t_fwd_rows_kernel<32, true, 2>), grid, dim3(256), 0, st, x, w, bias, y, B, H, W, RB, ni);
+    else hipLaunchKernelGGL((s1t_fwd_rows_kernel<32, false, 2>), grid, dim3(256), 0, st, x, w, bias, y, B, H, W, RB, ni);
+  } else {
+    if (stats) hipLaunchKernelGGL((s1t_fwd_rows_kernel<32, true, 1>), grid, dim3(256), 0, st, x, w, bias, y, B, H, W, RB, ni);
+    else hipLaunchKernelGGL((s1t_fwd_rows_kernel<32, false, 1>), grid, dim3(256), 0, st, x, w, bias, y, B, H, W, RB, ni);
+  }
   LG_CHECK_LAUNCH("lg_n3_s1t_fwd_rows");
   lg_note_kernel(stats ? "s1t_fwd_rows_kernel<32,NORM>" : "s1t_fwd_rows_kernel<32>");
   return LG_OK;

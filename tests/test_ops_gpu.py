@@ -381,11 +381,12 @@ def test_n3_tap_product_kernels_from_bf16_mirror(ops, case):
     assert rel(dw1, O.conv2d_bwd(_bf16_round(x3), w1, dzr, 2)[1]) < 3e-5
 
 
-@pytest.mark.parametrize("case", [(2, 16, 16, 32), (1, 80, 48, 32), (1, 144, 16, 32)])
+@pytest.mark.parametrize("case", [(2, 16, 16, 32), (1, 80, 48, 32), (1, 144, 16, 32), (2, 16, 32, 32), (1, 80, 64, 32), (1, 48, 96, 32), (3, 80, 160, 32)])
 def test_final_layer_normalises_while_staging(ops, case):
     """lg_convT_s1_tanh_fwd_z16 (n3_rows.hip): InstanceNorm + LeakyReLU applied to the raw bf16 conv output while the final
     layer stages it == the stand-alone apply pass followed by the same layer, bit for bit; and both match the oracle on the
-    rounded operands.  Shapes cover one and several row blocks per strip (64 rows each) and a ragged last one."""
+    rounded operands.  Shapes cover one and several row blocks per strip (64 rows each) and a ragged last one; W % 32 == 0 takes the
+    pixel-pair form of the kernel (two output pixels per MFMA row, 32-column strips: one strip, partly idle blocks, two blocks per row)."""
     B, H, W, C = case
     rng = np.random.default_rng(zlib_crc(case) + 1)
     z = dev(r32(rng, B, H, W, C, scale=1.3) + 0.2)
