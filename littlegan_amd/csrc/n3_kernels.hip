@@ -222,10 +222,14 @@ __global__ __launch_bounds__(256) void n3_wgrad_kernel(const float* __restrict__
 // operands with ds_read_b64_tr_b16 (k = pixel is the row index); the 3-channel operand is gathered from the fp32 halo
 // as 8 consecutive pixels per lane and rounded to bf16 (RNE) — v_mfma_f32_32x32x16_bf16, 16 pixels per instruction
 // instead of 2, fp32 accumulate.  A k step = one tile row of 16 pixels; wave w owns tile rows 2w and 2w+1.
-template <int NT>
+// TH (8 | 16) = rows of a tile.  The kernel is bound by the bytes it keeps in flight (one tile ahead in registers, 3 | 2 blocks per CU at
+// 160 | 256 VGPRs: 33 | 49 KB per CU against the ~62 KB that 8 TB/s x 2 us ask for): TH = 16 doubles the tile of the 32-channel stride-1
+// layer (the final layer's weight gradient) at the same block count — 8 more VGPRs of staging registers.
+template <int NT, int TH = 8>
 __global__ __launch_bounds__(256) void n3_wgrad16_kernel(const float* __restrict__ big3, const __bf16* __restrict__ small16,
                                                          float* __restrict__ slab, int B, int H, int W, int s, int pad) {
-  constexpr int Cs = NT * 32, TH = 8, TW = 16;
+  static_assert(TH == 8 || (TH == 16 && NT == 1), "tile heights");
+  constexpr int Cs = NT * 32, TW = 16;
   constexpr int RSB = Cs * 2 + 16;                       // bytes per pixel row of sB (16-B pad)
   constexpr int SB_BYTES = (TH * TW * RSB > 75 * Cs * 4) ? TH * TW * RSB : 75 * Cs * 4;  // also the merge buffer
   extern __shared__ __attribute__((aligned(16))) char smem16[];
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256) void n3_wgrad16_kernel(const float* __restrict
   //  s_waitcnt / barriers 51 - 67 % of their cycles — costs 256 / 208 VGPRs and the resident blocks that hide the rest: conv1 weight
   //  gradient 83 -> 102 us, final 177 -> 290 us at B = 256.  Dropped.)
   constexpr int NPB = TH * TW * (Cs / 8) / 256;          // 16-B pieces of the wide operand per thread (2 | 4)
-  constexpr int NPA = (20 * 36 * 3 + 255) / 256;         // halo floats per thread, s = 2 (the larger halo): 9
+  constexpr int NPA = TH == 16 ? (20 * 20 * 3 + 255) / 256 : (20 * 36 * 3 + 255) / 256;   // halo floats per thread: TH = 16 is stride 1 only (5); s = 2 (the larger halo): 9
   u32x4 rb[NPB];
   float ra[NPA];
   auto tile_load = [&](int tile) {
@@ -300,8 +304,8 @@ __global__ __launch_bounds__(256) void n3_wgrad16_kernel(const float* __restrict
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) tile_load(tile + gridDim.x);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int ly = 2 * wid + ks;  // tile row = the 16 pixels of this k step
+    for (int ks = 0; ks < TH / 4; ++ks) {
+      const int ly = (TH / 4) * wid + ks;  // tile row = the 16 pixels of this k step
       bf16x8 a[3], b[NT];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -430,7 +434,10 @@ extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void
   if (ws_bytes < lg_n3_wgrad_workspace_bytes(B, H, W, Cs)) return LG_ERR_UNSUPPORTED;
   if (!big3 || (!small && !small16)) return LG_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  const int ntiles = B * (H / 8) * (W / 16), nblk = wgrad_blocks(ntiles, Cs);
+  static int th8 = -1;
+  if (th8 < 0) th8 = getenv("LG_N3W_TH8") ? 1 : 0;   // A/B switch
+  const bool th16 = Cs == 32 && s == 1 && H % 16 == 0 && small16 && !getenv("LG_N3W_F32") && !th8;   // 16-row tiles (bf16 path, final layer)
+  const int ntiles = B * (H / (th16 ? 16 : 8)) * (W / 16), nblk = wgrad_blocks(ntiles, Cs);
   const size_t lds = (size_t)(128 * Cs + (s * 8 + 4) * (s * 16 + 4) * 3 + 4) * 4;
   const __bf16* s16 = (const __bf16*)small16;
   static bool a = false;
@@ -441,8 +448,9 @@ extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void
   }
   float* slab = (float*)workspace;
   if (s16 && !getenv("LG_N3W_F32")) {  // bf16 path: bf16 MFMA straight from the mirror
-    auto ldsz = [&](int cs) { const size_t sb = (size_t)128 * (cs * 2 + 16), mg = (size_t)75 * cs * 4; return (sb > mg ? sb : mg) + (size_t)((s * 8 + 4) * (s * 16 + 4) * 3 + 4) * 4; };
-    if (Cs == 32) hipLaunchKernelGGL((n3_wgrad16_kernel<1>), dim3(nblk), dim3(256), ldsz(32), st, big3, s16, slab, B, H, W, s, pad);
+    auto ldsz = [&](int cs, int th = 8) { const size_t sb = (size_t)th * 16 * (cs * 2 + 16), mg = (size_t)75 * cs * 4; return (sb > mg ? sb : mg) + (size_t)((s * th + 4) * (s * 16 + 4) * 3 + 4) * 4; };
+    if (th16) hipLaunchKernelGGL((n3_wgrad16_kernel<1, 16>), dim3(nblk), dim3(256), ldsz(32, 16), st, big3, s16, slab, B, H, W, s, pad);
+    else if (Cs == 32) hipLaunchKernelGGL((n3_wgrad16_kernel<1>), dim3(nblk), dim3(256), ldsz(32), st, big3, s16, slab, B, H, W, s, pad);
     else hipLaunchKernelGGL((n3_wgrad16_kernel<2>), dim3(nblk), dim3(256), ldsz(64), st, big3, s16, slab, B, H, W, s, pad);
   } else if (Cs == 32) {
     if (s16) hipLaunchKernelGGL((n3_wgrad_kernel<1, true>), dim3(nblk), dim3(256), lds, st, big3, small, s16, slab, B, H, W, s, pad);
@@ -452,7 +460,7 @@ extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void
     else hipLaunchKernelGGL((n3_wgrad_kernel<2, false>), dim3(nblk), dim3(256), lds, st, big3, small, s16, slab, B, H, W, s, pad);
   }
   LG_CHECK_LAUNCH("lg_n3_wgrad");
-  lg_note_kernel((s16 && !getenv("LG_N3W_F32")) ? (Cs == 32 ? "n3_wgrad16_kernel<1>" : "n3_wgrad16_kernel<2>") : "n3_wgrad_kernel<f32>");
+  lg_note_kernel((s16 && !getenv("LG_N3W_F32")) ? (th16 ? "n3_wgrad16_kernel<1,16>" : Cs == 32 ? "n3_wgrad16_kernel<1>" : "n3_wgrad16_kernel<2>") : "n3_wgrad_kernel<f32>");
   const int n = 75 * Cs;
   hipLaunchKernelGGL(n3_slab_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, st, (const float*)workspace, dw, nblk, n,
                      accumulate);
