@@ -268,7 +268,14 @@ class Decoder(_ConvStack):
         packs = self.packs()
         saved = []
         if add[0] is not None:  # tiny (init_dim^2 x conv_filter[0]); later skips are fused into the norm-apply pass
-            x = x + (torch.cat(add[0], 0) if isinstance(add[0], tuple) else add[0])
+            if isinstance(add[0], tuple):  # (first rows, remaining rows) of the batch: two adds into one new tensor, no concatenated copy
+                b1 = add[0][0].shape[0]
+                xs = torch.empty_like(x)
+                torch.add(x[:b1], add[0][0], out=xs[:b1])
+                torch.add(x[b1:], add[0][1], out=xs[b1:])
+                x = xs
+            else:
+                x = x + add[0]
         m16 = self.dtype == DT_BF16
         # level 1's input (dense + norm output, plus the first skip) is tiny: its bf16 mirror is a plain cast
         x16 = x.to(torch.bfloat16) if m16 else None

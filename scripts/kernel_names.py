@@ -49,8 +49,10 @@ def parse(name):
 def short(name):
     base, a = parse(name)
     t = lambda i, d=None: a[i] if i < len(a) else d
-    if base == "conv_down3_kernel":      # <STATS, FUSE, PAIR = false, NW = 128>
-        return "conv_down3_kernel<PAIR>" if t(2) == "true" else f"conv_down3_kernel<NW={t(3, '128')}>"
+    if base == "conv_down3_kernel":      # <STATS, FUSE, PAIR = false, NW = 128, NORM = false>
+        if t(2) == "true":
+            return "conv_down3_kernel<PAIR>"
+        return f"conv_down3_kernel<NW={t(3, '128')}" + (",NORM>" if t(4) == "true" else ">")
     if base == "conv_up3_kernel":        # <CS, N, STATS, FUSE, NTT = tiles per step>; (64, 32) with one tile per step = the 4-wave form
         return f"conv_up3_kernel<{t(0)},{t(1)}" + (",4w>" if (t(1) == "32" and t(4, "2") == "1") else ">")
     if base == "conv_halo_kernel":       # <T, MODE, KCH, DBUF, SRC16, RES, ...>
@@ -69,8 +71,8 @@ def short(name):
         return f"wgrad_at_kernel<{t(0)},{t(1)}>"
     if base == "wgrad_kernel":           # <BF16, PATCH, SRC16, ...>
         return "wgrad_kernel<PATCH>" if t(1) == "true" else ("wgrad_kernel<bf16,per-tap>" if t(0) == "true" else "wgrad_kernel<f32,per-tap>")
-    if base == "n3_wgrad16_kernel":
-        return f"n3_wgrad16_kernel<{t(0)}>"
+    if base == "n3_wgrad16_kernel":      # <NT, TH = 8>
+        return f"n3_wgrad16_kernel<{t(0)}" + (",16>" if t(1) == "16" else ">")
     if base == "n3_wgrad_kernel":
         return "n3_wgrad_kernel<f32>"
     if base == "patch_p16_kernel":       # <S, N, OUT16, STATS, NF = false>

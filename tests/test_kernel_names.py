@@ -14,6 +14,10 @@ CASES = [
     ("conv_down3_kernel<true, false, false, 128>", "conv_down3_kernel<NW=128>"),
     ("conv_down3_kernel<false, true, false, 64>", "conv_down3_kernel<NW=64>"),
     ("conv_down3_kernel<true, false, true, 128>", "conv_down3_kernel<PAIR>"),
+    ("conv_down3_kernel<true, false, false, 128, true>", "conv_down3_kernel<NW=128,NORM>"),
+    ("conv_down3_kernel<true, false, false, 128, false>", "conv_down3_kernel<NW=128>"),
+    ("_ZN12_GLOBAL__N_119s1t_fwd_rows_kernelILi32ELb1ELi2EEEvPKDF16bPKfS4_PfiiiiNS_10RowsNormInE", "s1t_fwd_rows_kernel<32,NORM>"),
+    ("n3_wgrad16_kernel<1, 16>", "n3_wgrad16_kernel<1,16>"),
     ("conv_up3_kernel<128, 64, false, true>", "conv_up3_kernel<128,64>"),
     ("void (anonymous namespace)::conv_up3_kernel<64, 32, true, false>((anonymous namespace)::U3Params)", "conv_up3_kernel<64,32>"),
     ("conv_up3_kernel<64, 32, true, false, 1>", "conv_up3_kernel<64,32,4w>"),
