@@ -225,29 +225,38 @@ __global__ __launch_bounds__(256) void n3_wgrad_kernel(const float* __restrict__
 // TH (8 | 16) = rows of a tile.  The kernel is bound by the bytes it keeps in flight (one tile ahead in registers, 3 | 2 blocks per CU at
 // 160 | 256 VGPRs: 33 | 49 KB per CU against the ~62 KB that 8 TB/s x 2 us ask for): TH = 16 doubles the tile of the 32-channel stride-1
 // layer (the final layer's weight gradient) at the same block count — 8 more VGPRs of staging registers.
-template <int NT, int TH = 8>
+// The 3-channel operand lives in LDS as kx-SHIFTED bf16 PLANES (round 3, DESIGN 8b lever 2): plane (c3, kx) row y holds the 16 values
+// halo[y][S x' + kx][c3], x' = 0..15, so the A fragment of row (tap, c3) for the 16 pixels of a k step is ONE ds_read_b128 (8
+// consecutive x') at a compile-time-free address — it was 8 scalar LDS reads + 8 conversions per fragment, 24 per k step and lane,
+// out of a fp32 halo.  The planes are filled by scattering every halo value, rounded once, to the <= 5 (S = 1) | 3 (S = 2) planes it
+// appears in (2-byte stores, an invalid target goes to a per-thread dump slot: no branch).  Rows of (tap, c3) >= 75 read a zero region.
+template <int NT, int TH = 8, int S = 1>
 __global__ __launch_bounds__(256) void n3_wgrad16_kernel(const float* __restrict__ big3, const __bf16* __restrict__ small16,
-                                                         float* __restrict__ slab, int B, int H, int W, int s, int pad) {
-  static_assert(TH == 8 || (TH == 16 && NT == 1), "tile heights");
+                                                         float* __restrict__ slab, int B, int H, int W, int s_unused, int pad) {
+  static_assert(TH == 8 || (TH == 16 && NT == 1 && S == 1), "tile heights");   // (64 channels, stride 2 on 16-row tiles: 328 VGPRs, or 61 spills at two blocks per CU: 164 -> 248 us)
+  static_assert(S == 1 || S == 2, "strides");
+  constexpr int s = S;
   constexpr int Cs = NT * 32, TW = 16;
   constexpr int RSB = Cs * 2 + 16;                       // bytes per pixel row of sB (16-B pad)
   constexpr int SB_BYTES = (TH * TW * RSB > 75 * Cs * 4) ? TH * TW * RSB : 75 * Cs * 4;  // also the merge buffer
   extern __shared__ __attribute__((aligned(16))) char smem16[];
-  const int HH = s * TH + 4, HW = s * TW + 4;
-  char* sB = smem16;                                       // [128][RSB] bf16
-  float* sA = reinterpret_cast<float*>(smem16 + SB_BYTES);  // [HH*HW*3] fp32 halo of the 3-channel tensor
+  constexpr int HH = s * TH + 4, HW = s * TW + 4;
+  constexpr int PL_ZERO = 15 * HH * 32;                  // after the 15 planes: 16 + 1 zero rows (a k step adds up to s (TH - 1) rows)
+  constexpr int PL_DUMP = PL_ZERO + (s * TH + 1) * 32;   // then 256 x 2 B of dump slots
+  char* sB = smem16;                                       // [TH*16][RSB] bf16
+  char* sP = smem16 + SB_BYTES;                            // planes [3][5][HH][16] bf16 | zero rows | dump slots
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int tpx = W / TW, tpi = tpx * (H / TH), ntiles = B * tpi;
   const int Hb = s * H, Wb = s * W;
+  (void)s_unused;
   int aoff[3];
-  bool aval[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int idx = i * 32 + r;  // (tap, c3)
-    aval[i] = idx < 75;
     const int t = idx / 3, c3 = idx - t * 3;
-    aoff[i] = aval[i] ? ((t / 5) * HW + (t % 5)) * 3 + c3 : 0;
+    aoff[i] = (idx < 75 ? ((c3 * 5 + t % 5) * HH + t / 5) * 32 : PL_ZERO) + h * 16;
   }
+  for (int i = threadIdx.x; i < (s * TH + 1) * 8; i += 256) reinterpret_cast<unsigned*>(sP + PL_ZERO)[i] = 0u;   // (the first barrier of the tile loop publishes it)
   f32x16 acc[3][NT];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(256) void n3_wgrad16_kernel(const float* __restrict
   //  s_waitcnt / barriers 51 - 67 % of their cycles — costs 256 / 208 VGPRs and the resident blocks that hide the rest: conv1 weight
   //  gradient 83 -> 102 us, final 177 -> 290 us at B = 256.  Dropped.)
   constexpr int NPB = TH * TW * (Cs / 8) / 256;          // 16-B pieces of the wide operand per thread (2 | 4)
-  constexpr int NPA = TH == 16 ? (20 * 20 * 3 + 255) / 256 : (20 * 36 * 3 + 255) / 256;   // halo floats per thread: TH = 16 is stride 1 only (5); s = 2 (the larger halo): 9
+  constexpr int NPA = (HH * HW * 3 + 255) / 256;         // halo floats per thread: 3 (TH 8, S 1) | 5 (TH 16) | 9 (S 2)
   u32x4 rb[NPB];
   float ra[NPA];
   auto tile_load = [&](int tile) {
@@ -293,8 +302,17 @@ __global__ __launch_bounds__(256) void n3_wgrad16_kernel(const float* __restrict
     }
 #pragma unroll
     for (int u = 0; u < NPA; ++u) {
-      const int i = threadIdx.x + u * 256;
-      if (i < HH * HW * 3) sA[i] = ra[u];
+      const int i = threadIdx.x + u * 256, hp = i / 3, c3 = i - hp * 3, yrow = hp / HW, xh = hp - yrow * HW;
+      const __bf16 b = (__bf16)ra[u];
+      const unsigned short bits = __builtin_bit_cast(unsigned short, b);
+#pragma unroll
+      for (int j = 0; j < (S == 1 ? 5 : 3); ++j) {
+        const int kx = S == 1 ? j : (xh & 1) + 2 * j;   // S = 2: only the taps of this column's parity see it
+        const int d = xh - kx, xp = S == 1 ? d : d >> 1;
+        const bool ok = i < HH * HW * 3 && kx < 5 && d >= 0 && xp < 16;
+        const int off = ok ? ((c3 * 5 + kx) * HH + yrow) * 32 + xp * 2 : PL_DUMP + (int)threadIdx.x * 2;
+        *reinterpret_cast<unsigned short*>(sP + off) = bits;
+      }
     }
   };
   if ((int)blockIdx.x < ntiles) tile_load(blockIdx.x);
@@ -308,13 +326,7 @@ __global__ __launch_bounds__(256) void n3_wgrad16_kernel(const float* __restrict
       const int ly = (TH / 4) * wid + ks;  // tile row = the 16 pixels of this k step
       bf16x8 a[3], b[NT];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const float* ap = sA + ((s * ly) * HW + s * (8 * h)) * 3 + aoff[i];
-        bf16x8 v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = aval[i] ? (__bf16)ap[e * s * 3] : (__bf16)0.f;
-        a[i] = v;
-      }
+      for (int i = 0; i < 3; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sP + aoff[i] + s * ly * 32);
       const int row0 = ly * TW + 8 * (g >> 1) + lq;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -448,10 +460,16 @@ extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void
   }
   float* slab = (float*)workspace;
   if (s16 && !getenv("LG_N3W_F32")) {  // bf16 path: bf16 MFMA straight from the mirror
-    auto ldsz = [&](int cs, int th = 8) { const size_t sb = (size_t)th * 16 * (cs * 2 + 16), mg = (size_t)75 * cs * 4; return (sb > mg ? sb : mg) + (size_t)((s * th + 4) * (s * 16 + 4) * 3 + 4) * 4; };
-    if (th16) hipLaunchKernelGGL((n3_wgrad16_kernel<1, 16>), dim3(nblk), dim3(256), ldsz(32, 16), st, big3, s16, slab, B, H, W, s, pad);
-    else if (Cs == 32) hipLaunchKernelGGL((n3_wgrad16_kernel<1>), dim3(nblk), dim3(256), ldsz(32), st, big3, s16, slab, B, H, W, s, pad);
-    else hipLaunchKernelGGL((n3_wgrad16_kernel<2>), dim3(nblk), dim3(256), ldsz(64), st, big3, s16, slab, B, H, W, s, pad);
+    // LDS: the wide operand's tile (also the merge buffer) + the 15 shifted planes, their zero rows and the dump slots
+    auto ldsz = [&](int cs, int th = 8) {
+      const size_t sb = (size_t)th * 16 * (cs * 2 + 16), mg = (size_t)75 * cs * 4;
+      return (sb > mg ? sb : mg) + (size_t)15 * (s * th + 4) * 32 + (size_t)(s * th + 1) * 32 + 512;
+    };
+    if (th16) hipLaunchKernelGGL((n3_wgrad16_kernel<1, 16, 1>), dim3(nblk), dim3(256), ldsz(32, 16), st, big3, s16, slab, B, H, W, s, pad);
+    else if (Cs == 32 && s == 1) hipLaunchKernelGGL((n3_wgrad16_kernel<1, 8, 1>), dim3(nblk), dim3(256), ldsz(32), st, big3, s16, slab, B, H, W, s, pad);
+    else if (Cs == 32) hipLaunchKernelGGL((n3_wgrad16_kernel<1, 8, 2>), dim3(nblk), dim3(256), ldsz(32), st, big3, s16, slab, B, H, W, s, pad);
+    else if (s == 1) hipLaunchKernelGGL((n3_wgrad16_kernel<2, 8, 1>), dim3(nblk), dim3(256), ldsz(64), st, big3, s16, slab, B, H, W, s, pad);
+    else hipLaunchKernelGGL((n3_wgrad16_kernel<2, 8, 2>), dim3(nblk), dim3(256), ldsz(64), st, big3, s16, slab, B, H, W, s, pad);
   } else if (Cs == 32) {
     if (s16) hipLaunchKernelGGL((n3_wgrad_kernel<1, true>), dim3(nblk), dim3(256), lds, st, big3, small, s16, slab, B, H, W, s, pad);
     else hipLaunchKernelGGL((n3_wgrad_kernel<1, false>), dim3(nblk), dim3(256), lds, st, big3, small, s16, slab, B, H, W, s, pad);
