@@ -129,8 +129,14 @@ __device__ __forceinline__ u32x4 lg_norm8(const u32x4 z8, float mu, float mul, f
     float t0 = __builtin_bit_cast(float, z8[k] << 16), t1 = __builtin_bit_cast(float, z8[k] & 0xffff0000u);
     t0 = a * ((t0 - mu) - mul) + b; t1 = a * ((t1 - mu) - mul) + b;
     t0 = lg_leaky(t0, alpha); t1 = lg_leaky(t1, alpha);
+    // ONE v_cvt_pk_bf16_f32 per pair (RNE, as the scalar cast): converting the halves separately and or-ing them together costs 4
+    typedef __bf16 lg_bf16x2 __attribute__((ext_vector_type(2)));
+#ifdef LG_NORM8_OLD   // A/B builds only
     const __bf16 h0 = (__bf16)t0, h1 = (__bf16)t1;
     o[k] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+#else
+    o[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{t0, t1}, lg_bf16x2));
+#endif
   }
   return o;
 }
