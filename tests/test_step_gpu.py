@@ -32,7 +32,12 @@ pytestmark = pytest.mark.gpu
 
 TOLS = {"f32": dict(img=2e-5, loss=2e-5, grad_med=2e-5, grad_rms=5e-3, sfloor=2e-4),
         "bf16": dict(img=6e-2, loss=2e-2, grad_med=0.2, grad_rms=0.5, sfloor=0.4),   # vs fp64: loose, secondary
-        "bf16_emu": dict(img=4e-2, loss=2e-3, grad_med=4e-2, grad_rms=8e-2, sfloor=6e-2)}
+        # sfloor (1-element tensors: gamma / beta gradients, sums with heavy cancellation, bounded against the model's largest
+        # gradient): the EMULATING ORACLE ITSELF moves by 0.11 of that scale on such a scalar when the images it is fed at the model
+        # boundaries change in the last fp32 bit (round 3: the final layer's kernel began to add its taps in the opposite kx order —
+        # Adjuster norm beta at 128x128: oracle 0.011329 -> 0.009519, kernels 0.011319 -> 0.011492; tests/diagnostics/scalar_grad_noise.py).
+        # Twice that movement is the floor of this comparison; the tight checks are call by call (test_step_replay_gpu.py).
+        "bf16_emu": dict(img=4e-2, loss=2e-3, grad_med=4e-2, grad_rms=8e-2, sfloor=0.22)}
 
 
 def emu_reference(cfg, W, b, inp, fake, adj):
