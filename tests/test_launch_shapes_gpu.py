@@ -514,3 +514,39 @@ def test_whole_f32_step_at_c2_batch():
             else:
                 r = float((a - b).pow(2).mean().sqrt()) / (float(b.pow(2).mean().sqrt()) + 1e-30)
                 assert r < 5e-3, (m, i, r)   # (f32: a LeakyReLU pre-activation at rounding distance from 0 may flip between the two groupings)
+
+
+@pytest.mark.parametrize("layer", ["enc.conv2", "enc.conv3"])
+def test_normalising_down_conv_at_the_adjuster_batch(ops, layer):
+    """lg_conv2d_s2_fwd_stats_zn at the size the step launches it: D on the Adjuster's output, 2B = 512 images
+    (littlegan_amd/eager_trainer.py, Discriminator.forward_packed(top_only=True); reference eager_trainer.py:158-160).  The conv fed with
+    the RAW bf16 map of the level below + its statistics records == InstanceNorm + LeakyReLU apply pass followed by the conv on the
+    normalised map, bit for bit (result and moments) — that second path is the one test_forward_with_fused_moments checks against the
+    oracle at B = 512 — and == the same normalising conv on 32-image chunks (no cross-sample contamination: the statistics record
+    is picked per item).  Samples carry different statistics."""
+    _, _, cb, cs, s = next(l for l in LAYERS if l[0] == layer)
+    B = 512
+    zin = _rand((B, 2 * s, 2 * s, cb), 41, 1.0)
+    zin = zin * (0.5 + 2.0 * torch.rand(B, 1, 1, 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)))
+    zin = zin + _rand((B, 1, 1, 1), 5, 1.0)
+    gm_in, bt_in = torch.tensor([0.9], device="cuda"), torch.tensor([0.2], device="cuda")
+    gm, bt = torch.tensor([1.2], device="cuda"), torch.tensor([-0.1], device="cuda")
+    zin16 = torch.empty(zin.shape, dtype=torch.bfloat16, device="cuda")
+    st_in = ops.instnorm_stats(zin, gm_in, bt_in, 0, ALPHA, x16_out=zin16)
+    del zin
+    w = _rand((5, 5, cb, cs), 43, 0.05)
+    bias = _rand((cs,), 44, 0.1)
+    pack = ops.conv_pack(w, cb, cs, 1)
+    assert ops.conv2d_s2_fwd_stats_zn_supported(B, 2 * s, 2 * s, cb, cs, 1)
+    h16 = torch.empty_like(zin16)
+    ops.instnorm_apply(zin16, st_in, None, 0, 1, ALPHA, out16=h16, want_f32=False)
+    z_ref, st_ref = ops.conv2d_s2_fwd_stats(None, pack, bias, cs, 1, gm, bt, x16=h16, z16=True, alpha=ALPHA)
+    st_ref = ops.stats_tensor(st_ref)
+    del h16
+    z, st = ops.conv2d_s2_fwd_stats_zn(zin16, st_in, ALPHA, pack, bias, cs, 1, gm, bt)
+    assert "NORM" in ops.last_kernel()
+    assert torch.equal(z, z_ref) and torch.equal(st, st_ref)
+    for lo in range(0, B, CHUNK):
+        zc, sc = ops.conv2d_s2_fwd_stats_zn(zin16[lo:lo + CHUNK].contiguous(), st_in[lo:lo + CHUNK].contiguous(), ALPHA, pack, bias, cs, 1,
+                                            gm, bt)
+        assert torch.equal(zc, z[lo:lo + CHUNK]) and torch.equal(sc, st[lo:lo + CHUNK]), lo
