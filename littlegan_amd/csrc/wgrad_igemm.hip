@@ -403,12 +403,16 @@ extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void
 extern "C" size_t lg_wgrad_at_workspace_bytes(int B, int Hm, int Wm, int cb, int cs);
 extern "C" int lg_wgrad_at_try(const void* big16, const void* small16, void* workspace, size_t ws_bytes, int B, int Hm, int Wm,
                                int cb, int cs, int* nsplit_out, void* stream);
+extern "C" size_t lg_wgrad_at32_workspace_bytes(int B, int Hm, int Wm, int cb, int cs);
+extern "C" int lg_wgrad_at32_try(const float* big, const float* small, void* workspace, size_t ws_bytes, int B, int Hm, int Wm,
+                                 int cb, int cs, int* nsplit_out, void* stream);
 static size_t wgrad_ws_generic(int B, int Hm, int Wm, int cb, int cs, int dtype);
 
 extern "C" size_t lg_wgrad_workspace_bytes(int B, int Hm, int Wm, int cb, int cs, int dtype) {
   size_t g = wgrad_ws_generic(B, Hm, Wm, cb, cs, dtype);
   if (cb == 3) { const size_t n = lg_n3_wgrad_workspace_bytes(B, Hm, Wm, cs); if (n > g) g = n; }
   else if (dtype == LG_DT_BF16) { const size_t n = lg_wgrad_at_workspace_bytes(B, Hm, Wm, cb, cs); if (n > g) g = n; }
+  else { const size_t n = lg_wgrad_at32_workspace_bytes(B, Hm, Wm, cb, cs); if (n > g) g = n; }
   return g;
 }
 
@@ -455,6 +459,19 @@ extern "C" int lg_conv_wgrad_m16(const float* big, const void* big16, const floa
   if (cb != 3 && dtype == LG_DT_BF16 && big16 && small16) {  // all-taps kernel (wgrad_at.hip) on the 16x16 maps and larger
     int ns_at = 0;
     const int rc = lg_wgrad_at_try(big16, small16, workspace, ws_bytes, B, Hm, Wm, cb, cs, &ns_at, stream);
+    if (rc == LG_OK) {
+      const long long n4 = 25LL * cb * cs / 4;
+      const int rb4 = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+      hipLaunchKernelGGL(slab_reduce4_kernel, dim3(rb4), dim3(256), 0, (hipStream_t)stream, (const f32x4*)workspace, (f32x4*)dw,
+                         ns_at, n4, accumulate);
+      LG_CHECK_LAUNCH("lg_conv_wgrad(reduce)");
+      return LG_OK;
+    }
+    if (rc != LG_ERR_UNSUPPORTED) return rc;
+  }
+  if (cb != 3 && dtype == LG_DT_F32 && big && small && pstride == 2 && ppad == 1) {  // exact-f32 path: all-taps kernel (wgrad_at32.hip)
+    int ns_at = 0;
+    const int rc = lg_wgrad_at32_try(big, small, workspace, ws_bytes, B, Hm, Wm, cb, cs, &ns_at, stream);
     if (rc == LG_OK) {
       const long long n4 = 25LL * cb * cs / 4;
       const int rb4 = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);

@@ -69,6 +69,8 @@ def short(name):
         return "conv_igemm_kernel<%s>" % {"0": "DOWN", "1": "UP", "2": "S1T", "3": "PATCH"}.get(t(1), "?")
     if base == "wgrad_at_kernel":
         return f"wgrad_at_kernel<{t(0)},{t(1)}>"
+    if base == "wgrad_at32_kernel":
+        return f"wgrad_at32_kernel<{t(0)},{t(1)}>"
     if base == "wgrad_kernel":           # <BF16, PATCH, SRC16, ...>
         return "wgrad_kernel<PATCH>" if t(1) == "true" else ("wgrad_kernel<bf16,per-tap>" if t(0) == "true" else "wgrad_kernel<f32,per-tap>")
     if base == "n3_wgrad16_kernel":      # <NT, TH = 8>

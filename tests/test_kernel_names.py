@@ -27,6 +27,7 @@ CASES = [
     ("conv_up4_kernel<false, true, true>", "conv_up4_kernel<PAIR>"),
     ("conv_up4_kernel<true, false, false>", "conv_up4_kernel"),
     ("wgrad_at_kernel<16, 8>", "wgrad_at_kernel<16,8>"),
+    ("wgrad_at32_kernel<16, 4>", "wgrad_at32_kernel<16,4>"),
     ("patch_p16_kernel<1, 32, true, false, true>", "patch_p16_kernel<1,32,nf>"),
     ("patch_p16_kernel<2, 64, true, true, false>", "patch_p16_kernel<2,64>"),
     ("_ZN12_GLOBAL__N_119s1t_fwd_rows_kernelILi32ELb0EEEvPKDF16bPKfS4_PfiiiiNS_10RowsNormInE", "s1t_fwd_rows_kernel<32>"),

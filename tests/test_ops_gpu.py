@@ -88,6 +88,31 @@ def test_convT_s2_fwd_dgrad_wgrad(ops, case, dtype):
     assert rel(db, db_e) < 3e-5
 
 
+@pytest.mark.parametrize("case", [(2, 8, 16, 32, 64), (3, 4, 16, 64, 128), (2, 8, 8, 32, 64), (5, 8, 8, 64, 128), (1, 16, 32, 32, 64),
+                                  (2, 12, 16, 32, 192)])
+def test_f32_all_taps_weight_gradient(ops, case):
+    """wgrad_at32.hip (exact-f32 path, v_mfma_f32_32x32x2_f32, all 25 taps per block): both tilings (16 x 4 strips; whole 8-column
+    maps), odd batches, several (cb / 32) x (cs / 64) units, a map whose height is a multiple of 4 but not 8, in the conv and the
+    transposed-conv operand order, overwrite and accumulate — against the fp64 oracle at the f32 tolerance."""
+    B, Hm, Wm, cb, cs = case
+    rng = np.random.default_rng(zlib_crc(case) + 17)
+    big = r32(rng, B, 2 * Hm, 2 * Wm, cb)
+    small = r32(rng, B, Hm, Wm, cs)
+    w = r32(rng, 5, 5, cb, cs, scale=0.1)
+    dw_e = O.conv2d_bwd(big, w, small, 2)[1]          # conv: x = big, dy = small
+    dw = torch.full((5, 5, cb, cs), 3.0, device="cuda")
+    ops.conv2d_s2_wgrad(dev(big), dev(small), dw, False, 0)
+    assert ops.last_kernel().startswith("wgrad_at32_kernel"), ops.last_kernel()
+    assert rel(dw, dw_e) < TOL[0]
+    ops.conv2d_s2_wgrad(dev(big), dev(small), dw, True, 0)
+    assert rel(dw, 2 * dw_e) < TOL[0]
+    dwT_e = O.conv2d_transpose_bwd(small, w, big, 2)[1]   # transposed conv: x = small, dy = big
+    dwT = torch.zeros(5, 5, cb, cs, device="cuda")
+    ops.convT_s2_wgrad(dev(small), dev(big), dwT, False, 0)
+    assert ops.last_kernel().startswith("wgrad_at32_kernel")
+    assert rel(dwT, dwT_e) < TOL[0]
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("case", [(2, 6, 10, 32), (3, 16, 16, 32), (1, 4, 4, 64)])
 def test_convT_s1_tanh_fwd_bwd(ops, case, dtype):
