@@ -377,6 +377,9 @@ extern "C" int lg_conv_igemm_ex(int mode, int dtype, const float* src, const voi
   LG_CHECK_ARG((src || src16) && wpack && (out || out16), "lg_conv_igemm: null pointer");
   LG_CHECK_ARG(B > 0 && Hm > 0 && Wm > 0 && Cs > 0 && N > 0, "lg_conv_igemm: bad shape B=%d Hm=%d Wm=%d Cs=%d N=%d", B, Hm, Wm, Cs, N);
   LG_CHECK_ARG(dtype == LG_DT_F32 || dtype == LG_DT_BF16, "lg_conv_igemm: bad dtype %d", dtype);
+  // the exact-f32 kernels read the fp32 source and write the fp32 destination: bf16 mirrors alone are a bf16-dtype contract (a null
+  // fp32 pointer here would be dereferenced on the device)
+  LG_CHECK_ARG(dtype == LG_DT_BF16 || (src && out && !out16), "lg_conv_igemm: dtype f32 needs the fp32 source and destination (bf16 mirrors / bf16 output belong to dtype bf16)");
   LG_CHECK_ARG((long long)B * Hm * Wm < (1ll << 31) / 4, "lg_conv_igemm: M grid too large");
   ConvParams p{};
   p.src = src; p.wp = (const char*)wpack; p.bias = bias; p.out = out; p.out16 = (__bf16*)out16;

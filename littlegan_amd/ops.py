@@ -175,6 +175,8 @@ def conv2d_s2_dgrad(dy, pack, cb, dtype, out=None, dy16=None, out_bf16=False, fu
         _chk(dy, name="dy")
     if dy16 is not None:
         _chk16(dy16, dy if dy is not None else dy16, "dy16")
+    if dtype != DT_BF16 and (dy is None or out_bf16):
+        raise ValueError("conv2d_s2_dgrad: dtype f32 needs the fp32 gradient and writes fp32 (bf16 mirror / bf16 output: dtype bf16)")
     dev = (dy if dy is not None else dy16).device
     if out_bf16:
         out = torch.empty(B, 2 * Hs, 2 * Ws, cb, dtype=torch.bfloat16, device=dev)
@@ -260,6 +262,8 @@ def convT_s2_dgrad(dy, pack, cs, dtype, out=None, dy16=None, out_bf16=False, fus
         _chk(dy, name="dy")
     if dy16 is not None:
         _chk16(dy16, dy if dy is not None else dy16, "dy16")
+    if dtype != DT_BF16 and (dy is None or out_bf16):
+        raise ValueError("convT_s2_dgrad: dtype f32 needs the fp32 gradient and writes fp32 (bf16 mirror / bf16 output: dtype bf16)")
     dev = (dy if dy is not None else dy16).device
     if out_bf16:
         out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.bfloat16, device=dev)

@@ -22,6 +22,8 @@ sel = sys.argv[1:] or None
 for name, kind, Hs, cb, cs in LAYERS:
     if sel and not any(s in name for s in sel):
         continue
+    if dt == 0 and kind in ("ddown", "dup"):   # those rows time the bf16-mirror data gradients: no f32 form of that call
+        continue
     w = torch.randn(5, 5, cb, cs, device="cuda") * 0.05
     pack = ops.conv_pack(w, cb, cs, dt)
     small = torch.randn(B, Hs, Hs, cs, device="cuda")

@@ -671,3 +671,25 @@ def test_deferred_moments_finished_by_the_apply_launch(ops, case):
     # moments nobody applied: the stand-alone finalize
     _, mom2 = ops.convT_s2_fwd_stats(None, pack, dev(b), N, 1, gm, bt, x16=x16, z16=True, defer_stats=True)
     assert torch.equal(ops.stats_tensor(mom2), st_a)
+
+
+def test_f32_dtype_refuses_bf16_only_operands(ops):
+    """dtype f32 with only the bf16 mirror of the source (or a bf16 destination) is refused on both sides of the boundary: the exact-f32
+    kernels read the fp32 tensor, and a null fp32 pointer would be dereferenced on the device (found by scripts/bench_layer.py on the f32
+    path, round 3: 'Memory access fault by GPU').  The Python wrapper raises; the C entry point returns an error without launching."""
+    from littlegan_amd import _lib
+    B, H, cb, cs = 2, 8, 32, 64
+    w = torch.randn(5, 5, cb, cs, device="cuda") * 0.05
+    pack = ops.conv_pack(w, cb, cs, 0)
+    dz16 = torch.randn(B, 2 * H, 2 * H, cb, device="cuda").to(torch.bfloat16)
+    g16 = torch.randn(B, H, H, cs, device="cuda").to(torch.bfloat16)
+    with pytest.raises(ValueError):
+        ops.convT_s2_dgrad(None, pack, cs, 0, dy16=dz16, out_bf16=True)
+    with pytest.raises(ValueError):
+        ops.conv2d_s2_dgrad(None, pack, cb, 0, dy16=g16, out_bf16=True)
+    lib = _lib.load()
+    out16 = torch.empty(B, H, H, cs, dtype=torch.bfloat16, device="cuda")
+    rc = lib.lg_convT_s2_dgrad_m16(0, dz16.data_ptr(), pack.data_ptr(), 0, out16.data_ptr(), B, H, H, cb, cs, 0, 0)
+    assert rc != 0 and b"fp32 source" in lib.lg_last_error()
+    torch.cuda.synchronize()   # nothing was launched: the device is healthy
+    assert torch.isfinite(ops.conv2d_s2_fwd(torch.randn(B, 2 * H, 2 * H, cb, device="cuda"), pack, torch.zeros(cs, device="cuda"), cs, 0)).all()
