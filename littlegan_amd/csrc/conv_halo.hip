@@ -634,7 +634,17 @@ int launch(HaloParams p, hipStream_t st) {
 
 template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES = false>
 int dispatch_bn2(const HaloParams& p, hipStream_t st) {
-  if constexpr (!DBUF && !RES) {  // tall wave tiles (128 rows x 64/32 cols): half the weight-fragment traffic per MFMA
+  // exact-f32 path, 8 x 8 maps (two samples per row tile): at B = 64 that is 32 row tiles x 3 column tiles of 128 = 96 blocks for 256
+  // CUs (measured: conv4 forward takes the same 535 us at B = 64 and B = 128): 64-column tiles double the blocks.  An fp32 MFMA is 64
+  // cycles for two operand registers, so the narrower tile costs little operand traffic per matrix cycle.  (The choice depends on the
+  // map, not on the batch: a launch and its 32-image chunks must take the same tiling — the moment partials are compared bit for bit.)
+  bool narrow = false;
+  if constexpr (sizeof(T) == 4 && !DBUF && !RES) {
+    static int off = -1;
+    if (off < 0) off = getenv("LG_NO_F32_NARROW") ? 1 : 0;
+    narrow = !off && p.NI > 1 && p.Npad % 64 == 0;
+  }
+  if constexpr (!DBUF && !RES) if (!narrow) {  // tall wave tiles (128 rows x 64/32 cols): half the weight-fragment traffic per MFMA
     if (p.Npad % 256 == 0 && (p.cfg & 1)) return launch<T, MODE, KCH, DBUF, SRC16, RES, 1, 4, 4, 2>(p, st);
     if (p.Npad % 128 == 0 && (p.cfg & 2) && (!(MODE == MODE_DOWN && p.NI > 1) || (halo_w3_ok<T, MODE, KCH, SRC16, RES, 1, 4, 1>() && (p.cfg & 8)))) {
       if constexpr (halo_w3_ok<T, MODE, KCH, SRC16, RES, 1, 4, 1>()) {
@@ -644,8 +654,8 @@ int dispatch_bn2(const HaloParams& p, hipStream_t st) {
       return launch<T, MODE, KCH, DBUF, SRC16, RES, 1, 4, 4, 1>(p, st);
     }
   }
-  if (p.Npad % 128 == 0) return launch<T, MODE, KCH, DBUF, SRC16, RES, 2, 2, 2, 2>(p, st);
-  if (p.Npad % 64 == 0) {
+  if (p.Npad % 128 == 0 && !narrow) return launch<T, MODE, KCH, DBUF, SRC16, RES, 2, 2, 2, 2>(p, st);
+  if (p.Npad % 64 == 0) {   // (32-column tiles for the f32 8 x 8 level: conv4 forward 330 -> 305 us at B = 64, but the C2 step 9.08 -> 9.19 ms)
     if constexpr (!DBUF && halo_w3_ok<T, MODE, KCH, SRC16, RES, 2, 2, 1>()) {
       if (!(p.cfg & 16)) return launch<T, MODE, KCH, DBUF, SRC16, RES, 2, 2, 2, 1, true>(p, st);
     }
