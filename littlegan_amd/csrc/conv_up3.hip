@@ -28,9 +28,6 @@
 #include <utility>
 #include "lg_common.h"
 
-#ifndef LG_U3_PIECE_MODE
-#define LG_U3_PIECE_MODE 2
-#endif
 #ifndef LG_U3_NO_DEFER
 #define LG_U3_NO_DEFER 0
 #endif
@@ -293,16 +290,13 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
       static_assert(!DEFER || F >= NPC * STEP + 2, "class loop too short for the deferred row sweep");
       constexpr bool RD = DEFER && f >= 1 && (f - 1) % STEP == 0 && (f - 1) / STEP < NPC;
       constexpr bool ST = DEFER && f >= 1 + STEP && (f - 1 - STEP) % STEP == 0 && (f - 1 - STEP) / STEP < NPC;
-#if LG_U3_PIECE_MODE == 2
+      // The pieces sit between two sched_barrier(0) at the fragment boundary.  Handed to the group pipeline below as groups of their
+      // own (VMEM write, DS read), the piece read could be picked by ANY earlier "DS read" group: the whole class loop came out scrambled
+      // (ring waits collapsed to vmcnt(0..3), MFMAs of different fragments interleaved, 12 min of compile time).
       if constexpr (ST || RD) __builtin_amdgcn_sched_barrier(0);
-#endif
-#if LG_U3_PIECE_MODE != 0
       if constexpr (ST) piece_store((f - 1 - STEP) / STEP, rv);   // one register: piece q leaves, piece q + 1 is read behind it
       if constexpr (RD) rv = piece_lds((f - 1) / STEP);
-#endif
-#if LG_U3_PIECE_MODE == 2
       if constexpr (ST || RD) __builtin_amdgcn_sched_barrier(0);
-#endif
       if constexpr (LG_U3_SCHED == 0) {
         __builtin_amdgcn_sched_barrier(0);
       } else {  // one MFMA, one LDS read in its shadow, ..., the ring refill behind the last MFMA (see conv_down3.hip)
@@ -311,10 +305,6 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-#if LG_U3_PIECE_MODE == 1
-        if constexpr (ST) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // the piece store (its data arrived a STEP ago)
-        if constexpr (RD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the piece read
-#endif
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
     });
