@@ -30,14 +30,14 @@ PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense MFMA TFLOP/s, /opt/skills/guides/
 GFLOP_PER_IMAGE = {"c3": 27.03, "c2": 13.25, "c5": 108.1}  # c5: 256^2
 
 
-def make_args(workload, device):
+def make_args(workload, device, dtype=None):
     c3 = workload in ("c3", "c5")  # c5 = the C3 step at 256x256 (init_dim 16): the per-GPU share of BASELINE configs[4]
     return SimpleNamespace(
         batch_size=256 if c3 else 64, image_channel=3, noise_dim=93, init_dim=16 if workload == "c5" else 8,
         conv_filter=[384, 256, 128, 64, 32],
         kernel_size=5, leaky_alpha=0.3, dropout_rate=0.5, l1_lambda=0.02, lr=5e-5, beta_1=0.5, beta_2=0.9,
         use_gp=False, use_clip=True, clip_range=0.5, use_partition=True, partition_interval=4,
-        train_adj=c3, cond_dim=40, mfma_dtype="bf16" if c3 else "f32", device=device, seed=0, no_io=True)
+        train_adj=c3, cond_dim=40, mfma_dtype=dtype or ("bf16" if c3 else "f32"), device=device, seed=0, no_io=True)
 
 
 def synthetic_inputs(args, device, rank):
@@ -101,15 +101,30 @@ def spawn_ranks(a):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
-    proc = subprocess.Popen(cmd, env=env)
+    # own process group: on expiry of the wall limit (a rank stuck in init_process_group or in a collective) the launcher
+    # AND its rank processes are ended by group id — never by pattern — and the bench fails; nothing is started again
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+
+    def stop():
+        import signal
+        for sig, grace in ((signal.SIGTERM, 20), (signal.SIGKILL, 10)):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                return
+            try:
+                proc.wait(timeout=grace)
+                return
+            except subprocess.TimeoutExpired:
+                continue
     try:
-        rc = proc.wait()
+        rc = proc.wait(timeout=a.wall_limit)
+    except subprocess.TimeoutExpired:
+        stop()
+        print(f"bench.py: the {a.gpus}-rank run exceeded --wall-limit {a.wall_limit} s and was terminated", file=sys.stderr)
+        raise SystemExit(124)
     except BaseException:
-        proc.terminate()
-        try:
-            proc.wait(timeout=20)
-        except subprocess.TimeoutExpired:
-            proc.kill()
+        stop()
         raise
     raise SystemExit(rc)
 
@@ -120,6 +135,14 @@ def main():
     ap.add_argument("--steps", type=int, default=50)    # >= 50 timed steps after 15 warm-up (partition steps included)
     ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3")
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default=None,
+                    help="MFMA operand type (default: bf16 for c3 / c5, f32 for c2).  `--workload c3 --dtype f32` = the G+D+Adj "
+                         "B=256 step at the north star's 1e-4 loss tolerance (exact-f32 products)")
+    ap.add_argument("--dp-contention", default=None,
+                    help="one-GPU rehearsal of the all-reduces' CU footprint: comma list of workgroup counts K (e.g. 8,16,32,64); "
+                         "at the three GradSync.launch points K streaming read-add-write blocks run on the side stream")
+    ap.add_argument("--reserve-cus", type=int, default=None, help="CUs the persistent kernels leave free (default: 0 at N=1, dist.RESERVED_CUS_DP at N>1)")
+    ap.add_argument("--wall-limit", type=int, default=900, help="seconds the self-spawned N-rank run may take before it is terminated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="time the C2 CPU shape at its full batch 64 (minutes)")
     ap.add_argument("--no-graph-leg", action="store_true", help="skip the extra hipGraph-replay timing (profilers that collect counters cannot follow a graph capture)")
@@ -144,15 +167,17 @@ def main():
     device = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("LG_DIST_TIMEOUT_S", "300")))   # a missing rank fails the bench instead of hanging it
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=tmo)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
 
     from littlegan_amd import ops
     from littlegan_amd.eager_trainer import EagerTrainer
     from littlegan_amd.model import Adjuster, Decoder, Discriminator, Encoder, Generator
-    args = make_args(a.workload, str(device))
+    args = make_args(a.workload, str(device), a.dtype)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):  # stdout carries exactly ONE JSON line
         decoder, encoder = Decoder(args), Encoder(args)
@@ -172,6 +197,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.reserve_cus is not None:
+        tr.sync.reserve_cus(a.reserve_cus)
     b0 = 11  # batch_no > 10 so the Adjuster branch runs (eager_trainer.py:152); every 5th step is a partition step
     step = tr.graph_step if a.graph else tr.train_step_from_inputs
     for i in range(a.warmup):
@@ -187,6 +214,8 @@ def main():
     dt_own = time.perf_counter() - t0   # this rank's own time for its K steps (before the closing barrier)
     barrier()
     dt = time.perf_counter() - t0
+    tr.sync.time_waits = False          # only the timed region's waits count (the roofline / graph legs below add none)
+    n_wait_events = len(tr.sync.wait_events)
     if a.graph:  # per-launch HIP events cannot sit inside a replayed graph: the roofline leg times 5 eager steps afterwards
         ops.Profile.start()
         for i in range(5):
@@ -196,7 +225,7 @@ def main():
     losses = {k: float(v.item()) for k, v in tr.losses.items()}  # of the last TIMED step (before the graph-replay leg below)
     graph_ms = None
     profiled = any("rocprof" in (os.environ.get(k) or "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
-    if world == 1 and not a.graph and a.workload == "c3" and not a.no_graph_leg and not profiled:
+    if world == 1 and not a.graph and a.workload == "c3" and args.mfma_dtype == "bf16" and not a.no_graph_leg and not profiled:
         # the same steps replayed from captured HIP graphs (EagerTrainer.graph_step, bit-identical results): reported beside
         # the headline number, which stays the eager one (per-launch HIP events cannot sit inside a replayed graph)
         bg = b0 + a.warmup + a.steps
@@ -208,6 +237,60 @@ def main():
             tr.graph_step(bg + 30 + i, inp)
         torch.cuda.synchronize()
         graph_ms = (time.perf_counter() - tg) / 30 * 1e3
+    # ---- legs AFTER the headline region (they never touch `value`) --------------------------------------------------
+    def timed_steps(n, first):
+        torch.cuda.synchronize()
+        t_ = time.perf_counter()
+        for i in range(n):
+            tr.train_step_from_inputs(first + i, inp)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t_) / n * 1e3
+
+    b_next = b0 + a.warmup + a.steps + 100
+    clock = None
+    if world == 1 and not profiled:
+        # shader clock HELD under this step: one probe wave beside 20 steps (side stream; d s_memtime / d s_memrealtime in
+        # 1-ms windows, lg_clock_probe).  The persistent kernels leave ONE CU's worth of blocks free meanwhile so that the
+        # resident probe wave displaces none of them; the leg's own ms/step is printed beside the clock.
+        from littlegan_amd import _lib as lib
+        out5 = torch.zeros(5, dtype=torch.int64, device=device)
+        flag = torch.zeros(1, dtype=torch.int32, device=device)
+        side = torch.cuda.Stream(device=device)
+        was = tr.sync.reserved_cus
+        tr.sync.reserve_cus(max(was, 1))
+        timed_steps(5, b_next)
+        with torch.cuda.stream(side):
+            lib.check(lib.load().lg_clock_probe(out5.data_ptr(), flag.data_ptr(), 20000, side.cuda_stream), "lg_clock_probe")
+        ms_clk = timed_steps(20, b_next + 5)
+        flag.fill_(1)
+        torch.cuda.synchronize()
+        tr.sync.reserve_cus(was)
+        o = out5.tolist()
+        if o[1] > 0:
+            clock = {"mean_mhz": round(o[0] / o[1] * 100.0, 1), "min_window_mhz": round(o[2] / 1e3, 1), "max_window_mhz": round(o[3] / 1e3, 1),
+                     "windows_1ms": o[4], "leg_ms_per_step": round(ms_clk, 3),
+                     "method": "d s_memtime / d s_memrealtime x 100 MHz of one probe wave resident beside 20 further steps (after the timed region)"}
+        b_next += 100
+    contention = None
+    ks = [int(k) for k in a.dp_contention.split(",")] if a.dp_contention else ([32] if (world == 1 and a.workload == "c3" and args.mfma_dtype == "bf16" and not profiled) else [])
+    if world == 1 and ks:
+        # one-GPU rehearsal of data parallelism's CU contention: K streaming read-add-write workgroups on the side
+        # stream at the three GradSync.launch points, with the persistent grids at full size and with K CUs left free
+        contention = {"baseline_ms_per_step": round(timed_steps(20, b_next), 3), "threads_per_workgroup": 512, "passes": 2, "runs": []}
+        was = tr.sync.reserved_cus
+        for k in ks:
+            for reserve in (0, k):
+                tr.sync.reserve_cus(reserve)
+                tr.sync.rehearse(k)
+                timed_steps(5, b_next)
+                tr.sync.wait_events, tr.sync.time_waits = [], True
+                ms_k = timed_steps(20, b_next + 5)
+                tr.sync.time_waits = False
+                stall = sum(e0.elapsed_time(e1) for e0, e1 in tr.sync.wait_events) / 20
+                contention["runs"].append({"workgroups": k, "reserved_cus": reserve, "ms_per_step": round(ms_k, 3),
+                                           "wait_stall_ms_per_step": round(stall, 3)})
+        tr.sync.rehearse(0)
+        tr.sync.reserve_cus(was)
     dp_info = None
     if world > 1:
         import torch.distributed as dist
@@ -216,7 +299,7 @@ def main():
         dt = float(t.item())
         # per-rank view beside the MAX-reduced figure: each rank's own ms/step and how long its compute stream stalled in
         # GradSync.wait_all() (event pair on the compute stream; 0 = the three all-reduces were hidden under the backward)
-        wait_ms = sum(e0.elapsed_time(e1) for e0, e1 in tr.sync.wait_events) / max(a.steps, 1)
+        wait_ms = sum(e0.elapsed_time(e1) for e0, e1 in tr.sync.wait_events[:n_wait_events]) / max(a.steps, 1)
         mine = torch.tensor([dt_own / a.steps * 1e3, wait_ms], dtype=torch.float64, device=device)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -224,6 +307,7 @@ def main():
         waits = [float(x[1]) for x in allr]
         dp_info = {"per_rank_ms_per_step": {"min": round(min(own), 3), "max": round(max(own), 3)},
                    "allreduce_wait_ms_per_step": {"min": round(min(waits), 3), "max": round(max(waits), 3)},
+                   "reserved_cus": tr.sync.reserved_cus, "adam_order": "".join(tr.adam_order) + " (each set right after its own wait)",
                    "backend": a.backend, "launch": "eager (graph_step falls back to eager launches under data parallelism)",
                    "allreduce_payload_mb": {m: round((tr.store.model_range(m)[1] - tr.store.model_range(m)[0]) * 4 / 1e6, 2) for m in "DGA"}}
 
@@ -246,7 +330,7 @@ def main():
         # they are collected on this same command and committed (scripts/collect_profiles.sh -> scripts/pmc_traffic.py)
         traffic, traffic_src = None, None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_pmc_traffic.json")
-        if a.workload == "c3" and world == 1 and os.path.exists(tpath):
+        if a.workload == "c3" and dt_name == "bf16" and world == 1 and os.path.exists(tpath):
             rec = json.load(open(tpath)).get(tag)
             if rec:
                 traffic, traffic_src = rec["bytes_per_launch"], "profiles/r3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, offline; goes stale when the kernel changes)"
@@ -259,7 +343,8 @@ def main():
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dt_name, "data": "synthetic",
-            "config": {"workload": {"c3": "C3: 128x128x3 synthetic CelebA, batch 256/GPU, bf16 MFMA conv/transposed-conv + Adjuster branch",
+            "config": {"workload": {"c3": "C3: 128x128x3 synthetic CelebA, batch 256/GPU, bf16 MFMA conv/transposed-conv + Adjuster branch" if dt_name == "bf16" else
+                                          "C3 at exact f32 (not a BASELINE config; the north star's 1e-4 loss tolerance): 128x128x3 synthetic CelebA, batch 256/GPU, f32 MFMA + Adjuster branch",
                                     "c2": "C2: 128x128x3 synthetic CelebA, batch 64/GPU, exact-f32 MFMA, G+D step only",
                                     "c5": "C5 (per-GPU share): 256x256x3 synthetic CelebA, batch 256/GPU, bf16 MFMA + Adjuster branch"}[a.workload],
                        "global_batch": gb, "per_gpu_batch": args.batch_size, "image": args.init_dim * 16, "cond_dim": 40,
@@ -279,7 +364,8 @@ def main():
                          "step_algorithmic_tflops": round(GFLOP_PER_IMAGE[a.workload] * args.batch_size / ms, 2)},
             "graph_replay": None if graph_ms is None else {"ms_per_step": round(graph_ms, 3), "value": round(args.batch_size / graph_ms * 1e3, 2),
                                                                "note": "same steps, one captured hipGraph per step kind, 30 timed steps after the headline region"},
-            "data_parallel": dp_info,
+            "data_parallel": dp_info if dp_info is not None else ({"contention": contention} if contention else None),
+            "clock": clock,
             "losses_last_step": losses,
             "parity": "checked against the in-repo fp64 restatement (tests/); parity to TensorFlow 1.15 is UNPINNED",
         }

@@ -261,6 +261,21 @@ size_t lg_fid_stats_workspace_bytes(long long N, int D);
 int lg_fid_stats(const float* act, long long N, int D, double* mu, double* sigma, void* workspace, size_t ws_bytes,
                  void* stream);
 
+/* ---- run-time services (no reference counterpart: the reference has no distributed code and no clock to report) ---- */
+/* CU budget of the persistent kernels.  Under data parallelism RCCL's ring kernels occupy CUs on a side stream while the
+ * backward convs run (littlegan_amd/dist.py); every persistent launcher sizes its grid to lg_grid_cus() = CUs - reserved
+ * blocks-per-CU multiples, so that all of its blocks are resident from the start.  Process-wide, default 0. */
+int lg_device_cus(void);
+int lg_set_reserved_cus(int n);
+int lg_grid_cus(void);
+/* one-GPU rehearsal of an all-reduce's CU footprint (bench.py --dp-contention): `workgroups` blocks of `threads` (256 | 512)
+ * stream dst = 0.5 dst + src over n floats (n % 4 == 0), `passes` times — what a ring step does to the CUs it occupies */
+int lg_contention_probe(float* dst, const float* src, long long n, int workgroups, int threads, int passes, void* stream);
+/* one wave beside the step (launch it on a SIDE stream): shader clock held, in 1-ms windows, until *stop_flag != 0 (device
+ * memory) or max_ms have passed.  out5 = {d s_memtime, d s_memrealtime (100 MHz ticks), min window kHz, max window kHz,
+ * number of windows}: mean clock = out5[0] / out5[1] x 100 MHz */
+int lg_clock_probe(unsigned long long* out5, const int* stop_flag, long long max_ms, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,11 @@ SIGNATURES = {
     "lg_fid_stats_workspace_bytes": (Z, [L, I]),
     "lg_fid_stats": (I, [P, L, I, P, P, P, Z, P]),
     "lg_augment_drawn_workspace_bytes": (Z, [I]),
+    "lg_device_cus": (I, []),
+    "lg_set_reserved_cus": (I, [I]),
+    "lg_grid_cus": (I, []),
+    "lg_contention_probe": (I, [P, P, L, I, I, I, P]),
+    "lg_clock_probe": (I, [P, P, L, P]),
     "lg_augment_drawn": (I, [P, P, I, I, I, F, F, F, F, F, L, L, L, P, Z, P]),
 }
 

@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["capi.hip", "conv_igemm.hip", "conv_halo.hip", "conv_down3.hip", "conv_up3.hip", "n3_kernels.hip", "n3_pgemm.hip", "wgrad_igemm.hip", "pack.hip", "norm.hip", "dense.hip", "heads.hip", "loss_optim.hip", "augment.hip", "fid.hip", "wgrad_at.hip", "wgrad_at32.hip", "n3_rows.hip", "skinny_mfma.hip", "conv_up4.hip"]
+SOURCES = ["capi.hip", "conv_igemm.hip", "conv_halo.hip", "conv_down3.hip", "conv_up3.hip", "n3_kernels.hip", "n3_pgemm.hip", "wgrad_igemm.hip", "pack.hip", "norm.hip", "dense.hip", "heads.hip", "loss_optim.hip", "augment.hip", "fid.hip", "wgrad_at.hip", "wgrad_at32.hip", "n3_rows.hip", "skinny_mfma.hip", "conv_up4.hip", "runtime.hip"]
 LIB = os.path.join(PKG, "liblittlegan_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 

@@ -45,7 +45,7 @@ extern "C" int lg_n3_s1t_fwd_rows_try(const void* x16, const float* stats, float
                                       int B, int H, int W, int C, void* stream);
 static bool n3_enabled() {
   static int v = -1;
-  if (v < 0) v = getenv("LG_NO_N3") ? 0 : 1;  // A/B switch
+  if (v < 0) v = lg_env_flag("LG_NO_N3") ? 0 : 1;  // A/B switch
   return v == 1;
 }
 static inline const float* raw_pack(const void* pack, int cb, int cs, int dtype) {
@@ -70,7 +70,7 @@ extern "C" int lg_n3_conv1_p16_supported(int H, int W, int N);
 extern "C" int lg_conv_fwd_stats_fused(int up, int dtype, int B, int Hs, int Ws, int cb, int cs) {
   if (B <= 0 || Hs <= 0 || Ws <= 0) return 0;
   if (cb == 3) return (!up && dtype == LG_DT_BF16 && n3_enabled() && lg_n3_conv1_p16_supported(Hs, Ws, cs)) ? 1 : 0;
-  if (getenv("LG_NO_HALO")) return 0;
+  if (lg_env_flag("LG_NO_HALO")) return 0;
   if ((long long)Hs * Ws < 128 && !(Hs == 8 && Ws == 8)) return 0;  // > 2 samples per 128-row tile: no per-sample record
   return up ? lg_conv_halo_supported(1, dtype, B, Hs, Ws, cs, cb) : lg_conv_halo_supported(0, dtype, B, Hs, Ws, cb, cs);
 }
@@ -126,7 +126,7 @@ extern "C" int lg_conv_down3_zn_supported(int B, int Hm, int Wm, int Cs, int N);
 extern "C" int lg_conv_down3_zn_try(const void* z16, const float* zstats, float alpha, const void* wpack, const float* bias, void* out16,
                                     int B, int Hm, int Wm, int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, void* stream);
 extern "C" int lg_conv2d_s2_fwd_stats_zn_supported(int B, int Hs, int Ws, int cb, int cs, int dtype) {
-  return (dtype == LG_DT_BF16 && cb != 3 && !getenv("LG_NO_HALO") && lg_conv_down3_zn_supported(B, Hs, Ws, cb, cs)) ? 1 : 0;
+  return (dtype == LG_DT_BF16 && cb != 3 && !lg_env_flag("LG_NO_HALO") && lg_conv_down3_zn_supported(B, Hs, Ws, cb, cs)) ? 1 : 0;
 }
 extern "C" int lg_conv2d_s2_fwd_stats_zn(const void* z16, const float* zstats, float alpha, const void* pack, const float* bias,
                                          void* y16, int B, int Hs, int Ws, int cb, int cs, int dtype, void* spart,
@@ -268,7 +268,7 @@ extern "C" int lg_convT_s1_tanh_fwd_m16(const float* x, const void* x16, const v
 
 // 1 if lg_convT_s1_tanh_fwd_z16 runs this shape (InstanceNorm + LeakyReLU of the input applied while it is staged)
 extern "C" int lg_convT_s1_tanh_fwd_z16_supported(int H, int W, int cb, int cs, int dtype) {
-  return (dtype == LG_DT_BF16 && cb == 3 && n3_enabled() && !getenv("LG_NO_ROWS") && lg_n3_rows_supported(H, W, cs)) ? 1 : 0;
+  return (dtype == LG_DT_BF16 && cb == 3 && n3_enabled() && !lg_env_flag("LG_NO_ROWS") && lg_n3_rows_supported(H, W, cs)) ? 1 : 0;
 }
 
 // y = tanh(convT_s1(h) + bias) with h = bf16(LeakyReLU_alpha(a*((z - mu) - mu_lo) + beta)) formed on the fly from the raw

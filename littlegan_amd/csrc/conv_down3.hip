@@ -523,22 +523,22 @@ extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const 
 extern "C" int lg_conv_down3_zn_try(const void* z16, const float* zstats, float alpha, const void* wpack, const float* bias, void* out16,
                                     int B, int Hm, int Wm, int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, void* stream) {
   if (nparts_out) *nparts_out = 0;
-  if (!zstats || !spart || !nparts_out || N % 128 != 0 || getenv("LG_NO_D3_NORM")) return LG_ERR_UNSUPPORTED;
+  if (!zstats || !spart || !nparts_out || N % 128 != 0 || lg_env_flag("LG_NO_D3_NORM")) return LG_ERR_UNSUPPORTED;
   return down3_launch(z16, wpack, bias, out16, B, Hm, Wm, Cs, N, spart, spart_bytes, nparts_out, nullptr, 0, zstats, alpha, stream);
 }
 extern "C" int lg_conv_down3_zn_supported(int B, int Hm, int Wm, int Cs, int N) {
-  return (!getenv("LG_NO_D3_NORM") && N % 128 == 0 && Hm % TH == 0 && Wm % TW == 0 && lg_conv_down3_supported(B, Hm, Wm, Cs, N)) ? 1 : 0;
+  return (!lg_env_flag("LG_NO_D3_NORM") && N % 128 == 0 && Hm % TH == 0 && Wm % TW == 0 && lg_conv_down3_supported(B, Hm, Wm, Cs, N)) ? 1 : 0;
 }
 static int down3_launch(const void* src16, const void* wpack, const float* bias, void* out16, int B, int Hm, int Wm, int Cs, int N,
                         void* spart, size_t spart_bytes, int* nparts_out, const LgNormFuse* nf, size_t nf_bytes,
                         const float* nstats, float nalpha, void* stream) {
   if (nparts_out) *nparts_out = 0;
   static int off = -1;
-  if (off < 0) off = getenv("LG_NO_DOWN3") ? 1 : 0;  // A/B switch
+  if (off < 0) off = lg_env_flag("LG_NO_DOWN3") ? 1 : 0;  // A/B switch
   if (off || !src16 || !wpack || !out16) return LG_ERR_UNSUPPORTED;
   const bool pair = Hm == 8 && Wm == 8 && B % 2 == 0;  // 8 x 8 maps: a tile = two samples side by side
   static int no64 = -1;
-  if (no64 < 0) no64 = getenv("LG_NO_DOWN3_N64") ? 1 : 0;
+  if (no64 < 0) no64 = lg_env_flag("LG_NO_DOWN3_N64") ? 1 : 0;
   const bool n64 = N % 128 != 0 && N % 64 == 0 && !pair && !no64;  // 64-column tiles (2 x 2 waves)
   if (((Hm % TH || Wm % TW) && !pair) || Cs % KC || (N % 128 && !n64) || B <= 0) return LG_ERR_UNSUPPORTED;
   if ((long long)4 * Hm * Wm * Cs * 2 * 2 >= (1ll << 31)) return LG_ERR_UNSUPPORTED;  // buffer descriptor: two samples below the OOB offset
@@ -559,15 +559,10 @@ static int down3_launch(const void* src16, const void* wpack, const float* bias,
   if (fuse) p.nf = *nf;
   if (nstats && (!stats || n64 || pair)) return LG_ERR_UNSUPPORTED;
   p.nstats = nstats; p.nalpha = nalpha;
-  static int nblk = 0;
-  if (!nblk) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      hipDeviceProp_t pr;
-      if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
-    }
-    nblk = 2 * cus;
-    if (const char* e = getenv("LG_D3_BLOCKS_PER_CU")) nblk = (atoi(e) > 0 ? atoi(e) : 2) * cus;  // probe: 1 = a lone wave per SIMD
+  static int bpc = 0;   // resident blocks per CU
+  if (!bpc) {
+    bpc = 2;
+    if (const char* e = getenv("LG_D3_BLOCKS_PER_CU")) bpc = atoi(e) > 0 ? atoi(e) : 2;  // probe: 1 = a lone wave per SIMD
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_down3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_down3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
@@ -579,6 +574,7 @@ static int down3_launch(const void* src16, const void* wpack, const float* bias,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, true, false, 64>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<true, false, false, 128, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
   }
+  const int nblk = bpc * lg_grid_cus();   // every block resident from the start, also beside communication kernels (runtime.hip)
   const int grid = p.nitems < nblk ? p.nitems : nblk;
   hipStream_t st = (hipStream_t)stream;
   constexpr int LDS0 = D3L<false>::LDS_BYTES, LDS1 = D3L<true>::LDS_BYTES;
@@ -603,6 +599,6 @@ static int down3_launch(const void* src16, const void* wpack, const float* bias,
 
 extern "C" int lg_conv_down3_supported(int B, int Hm, int Wm, int Cs, int N) {
   const bool pair = Hm == 8 && Wm == 8 && B % 2 == 0;
-  const bool n64 = N % 128 != 0 && N % 64 == 0 && !pair && !getenv("LG_NO_DOWN3_N64");
-  return (!getenv("LG_NO_DOWN3") && B > 0 && ((Hm % TH == 0 && Wm % TW == 0) || pair) && Cs % KC == 0 && (N % 128 == 0 || n64)) ? 1 : 0;
+  const bool n64 = N % 128 != 0 && N % 64 == 0 && !pair && !lg_env_flag("LG_NO_DOWN3_N64");
+  return (!lg_env_flag("LG_NO_DOWN3") && B > 0 && ((Hm % TH == 0 && Wm % TW == 0) || pair) && Cs % KC == 0 && (N % 128 == 0 || n64)) ? 1 : 0;
 }

@@ -641,7 +641,7 @@ int dispatch_bn2(const HaloParams& p, hipStream_t st) {
   bool narrow = false;
   if constexpr (sizeof(T) == 4 && !DBUF && !RES) {
     static int off = -1;
-    if (off < 0) off = getenv("LG_NO_F32_NARROW") ? 1 : 0;
+    if (off < 0) off = lg_env_flag("LG_NO_F32_NARROW") ? 1 : 0;
     narrow = !off && p.NI > 1 && p.Npad % 64 == 0;
   }
   if constexpr (!DBUF && !RES) if (!narrow) {  // tall wave tiles (128 rows x 64/32 cols): half the weight-fragment traffic per MFMA

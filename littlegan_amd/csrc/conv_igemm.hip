@@ -335,7 +335,7 @@ extern "C" int lg_conv_halo_try(int mode, int dtype, const float* src, const voi
 
 static bool halo_enabled() {
   static int v = -1;
-  if (v < 0) v = getenv("LG_NO_HALO") ? 0 : 1;  // A/B switch: LG_NO_HALO=1 forces the per-tap gather kernel
+  if (v < 0) v = lg_env_flag("LG_NO_HALO") ? 0 : 1;  // A/B switch: LG_NO_HALO=1 forces the per-tap gather kernel
   return v == 1;
 }
 

@@ -500,14 +500,10 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
 template <int CS, int N, int NTT = 2 / (N / 32)>
 int launch_up3(U3Params p, bool stats, hipStream_t st, bool fuse = false) {
   using C = Cfg<CS, N, NTT>;
-  static int nblk = 0;
-  if (!nblk) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      hipDeviceProp_t pr;
-      if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
-    }
-    nblk = (C::NWAVES == 8 ? 1 : 2) * cus;  // one 8-wave workgroup per CU, or two independent 4-wave ones
+  static bool attr_set = false;
+  const int nblk = (C::NWAVES == 8 ? 1 : 2) * lg_grid_cus();  // one 8-wave workgroup per CU, or two independent 4-wave ones
+  if (!attr_set) {
+    attr_set = true;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, true, false, NTT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false, false, NTT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false, true, NTT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
@@ -523,7 +519,7 @@ int launch_up3(U3Params p, bool stats, hipStream_t st, bool fuse = false) {
 }  // namespace
 
 extern "C" int lg_conv_up3_supported(int B, int Hm, int Wm, int Cs, int N) {
-  return (!getenv("LG_NO_UP3") && B > 0 && Hm % TH == 0 && Wm % TW == 0 && ((Cs == 128 && N == 64) || (Cs == 64 && N == 32))) ? 1 : 0;
+  return (!lg_env_flag("LG_NO_UP3") && B > 0 && Hm % TH == 0 && Wm % TW == 0 && ((Cs == 128 && N == 64) || (Cs == 64 && N == 32))) ? 1 : 0;
 }
 
 // LG_OK: launched.  LG_ERR_UNSUPPORTED: the caller falls back to conv_halo.hip.  *nparts_out = records per sample (tiles).
@@ -555,7 +551,7 @@ extern "C" int lg_conv_up3_nf_try(const void* src16, const void* wpack_up, const
   // N = 32: two independent 4-wave workgroups per CU, one tile per step (LG_U3_T4_8W=1: the round-2 form, one 8-wave workgroup
   // with two tiles per step)
   static int t4_8w = -1;
-  if (t4_8w < 0) t4_8w = getenv("LG_U3_T4_8W") ? 1 : 0;
+  if (t4_8w < 0) t4_8w = lg_env_flag("LG_U3_T4_8W") ? 1 : 0;
   // the norm-backward sums are produced by the one-tile-per-step forms only: with two tiles per step a thread's row sweep covers
   // both tiles, i.e. possibly two samples, and the per-thread sums would mix them (no layer of the step asks for that form)
   const bool fuse = (Cs == 128 || !t4_8w) && nf && nf->z && nf->stats && nf->part && nparts_out && (size_t)B * p.tpi * 2 * sizeof(double) <= nf_bytes;

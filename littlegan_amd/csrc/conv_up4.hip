@@ -373,8 +373,8 @@ __global__ __launch_bounds__(256, 2) void conv_up4_kernel(const U4Params p) {
 }  // namespace
 
 extern "C" int lg_conv_up4_supported(int B, int Hm, int Wm, int Cs, int N) {
-  const bool pair = Hm == 8 && Wm == 8 && B % 2 == 0 && !getenv("LG_NO_UP4_PAIR");   // 8 x 8 maps: a tile = two samples
-  return (!getenv("LG_NO_UP4") && B > 0 && ((Hm % TH == 0 && Wm % TW == 0) || pair) && Cs % KC == 0 && N % 128 == 0 &&
+  const bool pair = Hm == 8 && Wm == 8 && B % 2 == 0 && !lg_env_flag("LG_NO_UP4_PAIR");   // 8 x 8 maps: a tile = two samples
+  return (!lg_env_flag("LG_NO_UP4") && B > 0 && ((Hm % TH == 0 && Wm % TW == 0) || pair) && Cs % KC == 0 && N % 128 == 0 &&
           (long long)Hm * Wm * Cs * 2 * 2 < (1ll << 31)) ? 1 : 0;   // (two samples below the out-of-range offset of the halo loads)
 }
 
@@ -385,13 +385,13 @@ extern "C" int lg_conv_up4_nf_try(const void* src16, const void* wpack_up, const
                                   size_t nf_bytes, void* stream) {
   if (nparts_out) *nparts_out = 0;
   static int off = -1;
-  if (off < 0) off = getenv("LG_NO_UP4") ? 1 : 0;
+  if (off < 0) off = lg_env_flag("LG_NO_UP4") ? 1 : 0;
   if (off || !src16 || !wpack_up || !out16 || !lg_conv_up4_supported(B, Hm, Wm, Cs, N)) return LG_ERR_UNSUPPORTED;
   U4Params p{};
   p.src = (const __bf16*)src16; p.wp = (const char*)wpack_up; p.bias = bias; p.out = (__bf16*)out16;
   p.B = B; p.Hs = Hm; p.Ws = Wm; p.Cs = Cs; p.N = N; p.N32 = N / 32; p.KB = Cs / 16;
   static int nopair = -1;
-  if (nopair < 0) nopair = getenv("LG_NO_UP4_PAIR") ? 1 : 0;
+  if (nopair < 0) nopair = lg_env_flag("LG_NO_UP4_PAIR") ? 1 : 0;
   const bool pair = Hm == 8 && Wm == 8 && B % 2 == 0 && !nopair;
   p.tpi_x = pair ? 1 : Wm / TW; p.tpi = pair ? 1 : p.tpi_x * (Hm / TH); p.ntn = N / 128;
   const long long nper = (long long)(pair ? B / 2 : B) * p.tpi * p.ntn;
@@ -404,14 +404,10 @@ extern "C" int lg_conv_up4_nf_try(const void* src16, const void* wpack_up, const
   if (!nf && spart && nparts_out && !stats) return LG_ERR_UNSUPPORTED;
   p.spart = stats ? (double*)spart : nullptr;
   if (fuse) p.nf = *nf;
-  static int nblk = 0;
-  if (!nblk) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      hipDeviceProp_t pr;
-      if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
-    }
-    nblk = 2 * cus;
+  static bool attr_set = false;
+  const int nblk = 2 * lg_grid_cus();
+  if (!attr_set) {
+    attr_set = true;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_up4_kernel<true, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_up4_kernel<false, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_up4_kernel<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

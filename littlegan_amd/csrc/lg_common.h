@@ -25,6 +25,12 @@ extern "C" void lg_set_error(const char* fmt, ...);
 // bench.py reads it back through lg_last_kernel() so that its roofline line names a KERNEL, not a class of kernels.
 extern "C" void lg_note_kernel(const char* name);
 
+// 1 if the environment variable is set to a non-empty value; read ONCE per process at its first use (runtime.hip), so a
+// *_supported query and the launch it promises always agree.  `name` must be a string literal.
+extern "C" int lg_env_flag(const char* name);
+// CUs the persistent kernels may fill: device CUs minus those reserved for communication kernels (lg_set_reserved_cus)
+extern "C" int lg_grid_cus(void);
+
 #define LG_CHECK_ARG(cond, ...)            \
   do {                                     \
     if (!(cond)) {                         \

@@ -352,7 +352,7 @@ static int patch_grid(int ntiles, int per_cu) {  // per_cu: resident blocks per 
     cus = 256;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
   }
-  const int nb = forced > 0 ? forced : per_cu * cus;
+  const int nb = forced > 0 ? forced : per_cu * (cus < lg_grid_cus() ? cus : lg_grid_cus());
   return ntiles < nb ? ntiles : nb;
 }
 

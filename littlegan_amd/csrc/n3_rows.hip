@@ -227,14 +227,14 @@ extern "C" int lg_n3_rows_supported(int H, int W, int C) { return (W % 16 == 0 &
 extern "C" int lg_n3_s1t_fwd_rows_try(const void* x16, const float* stats, float alpha, const float* w, const float* bias, float* y,
                                       int B, int H, int W, int C, void* stream) {
   static int off = -1;
-  if (off < 0) off = getenv("LG_NO_ROWS") ? 1 : 0;
+  if (off < 0) off = lg_env_flag("LG_NO_ROWS") ? 1 : 0;
   if (off || !lg_n3_rows_supported(H, W, C) || !x16 || !w || !bias || !y) return LG_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int RB = H <= 64 ? H : 64;
   const RowsNormIn ni{stats, alpha};
   const __bf16* x = (const __bf16*)x16;
   static int no2 = -1;
-  if (no2 < 0) no2 = getenv("LG_ROWS_XJ1") ? 1 : 0;   // A/B switch: the one-pixel-per-row form everywhere
+  if (no2 < 0) no2 = lg_env_flag("LG_ROWS_XJ1") ? 1 : 0;   // A/B switch: the one-pixel-per-row form everywhere
   const bool xj2 = W % 32 == 0 && !no2;
   const int sw = xj2 ? 32 : 16;
   const dim3 grid(B * ((W + 4 * sw - 1) / (4 * sw)) * ((H + RB - 1) / RB));

@@ -1,0 +1,113 @@
+// Run-time services of the library that are not part of the step's arithmetic:
+//   * the CU budget of the persistent kernels (lg_set_reserved_cus / lg_grid_cus): under data parallelism RCCL's ring
+//     kernels run on a side stream WHILE the backward convs run (littlegan_amd/dist.py); a persistent grid sized to every CU
+//     assumes all of its blocks are resident from t = 0, and a block displaced by a communication workgroup becomes a
+//     serial tail of one block life.  Persistent launchers size their grids to lg_grid_cus() = CUs - reserved.
+//   * lg_contention_probe: the one-GPU rehearsal of that situation (bench.py --dp-contention K): K workgroups that stream
+//     read-add-write over a gradient-sized range, i.e. what one RCCL ring step does to the CUs it occupies.
+//   * lg_clock_probe: one wave that sits beside the step on a side stream and measures the shader clock the chip HOLDS
+//     (d s_memtime / d s_memrealtime x 100 MHz, MI355X_MICROARCH.md "DVFS give-back" item 6) in 1-ms windows until a flag in
+//     device memory is raised or its tick budget is spent — an exit condition the wave always reaches.
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include "lg_common.h"
+#include "../../include/littlegan_hip.h"
+
+static int g_reserved_cus = 0;
+
+static int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    cus = 256;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+      cus = pr.multiProcessorCount;
+  }
+  return cus;
+}
+
+extern "C" int lg_device_cus(void) { return device_cus(); }
+
+extern "C" int lg_set_reserved_cus(int n) {
+  LG_CHECK_ARG(n >= 0 && n < device_cus(), "lg_set_reserved_cus: %d of %d CUs", n, device_cus());
+  g_reserved_cus = n;
+  return LG_OK;
+}
+
+extern "C" int lg_grid_cus(void) { return device_cus() - g_reserved_cus; }
+
+// One switch table for the whole library: every A/B environment switch is read ONCE, at its first use, through this
+// function, so a *_supported query and the launch it promises can never see two different values.
+extern "C" int lg_env_flag(const char* name) {
+  struct Slot { const char* name; int val; };
+  static Slot slots[64];
+  static int n = 0;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < n; ++i)
+    if (slots[i].name == name || strcmp(slots[i].name, name) == 0) return slots[i].val;
+  const char* e = getenv(name);
+  const int v = (e && *e) ? 1 : 0;
+  if (n < 64) { slots[n].name = name; slots[n].val = v; ++n; }
+  return v;
+}
+
+namespace {
+
+__global__ __launch_bounds__(512) void contention_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n4,
+                                                         int passes) {
+  // dst = 0.5 dst + src: bounded whatever the number of passes; 16-B accesses, grid-stride
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (int p = 0; p < passes; ++p)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      const f32x4 a = reinterpret_cast<const f32x4*>(src)[i];
+      f32x4 d = reinterpret_cast<f32x4*>(dst)[i];
+      d = d * 0.5f + a;
+      reinterpret_cast<f32x4*>(dst)[i] = d;
+    }
+}
+
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* __restrict__ out, const int* stop,
+                                                         unsigned long long max_ticks, unsigned window_ticks) {
+  // one wave; lane 0 writes.  out: [0] d memtime, [1] d realtime (100 MHz), [2] min window kHz, [3] max window kHz, [4] windows
+  const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime(), t_begin = __builtin_amdgcn_s_memtime();
+  unsigned long long r0 = r_begin, t0 = t_begin, lo = ~0ull, hi = 0, nwin = 0;
+  for (;;) {
+    __builtin_amdgcn_s_sleep(64);
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (r1 - r0 >= window_ticks) {
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+      const unsigned long long khz = (t1 - t0) * 100000ull / (r1 - r0);   // cycles per 10-ns tick x 1e5 = kHz
+      lo = khz < lo ? khz : lo;
+      hi = khz > hi ? khz : hi;
+      ++nwin;
+      r0 = r1; t0 = t1;
+      if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || r1 - r_begin >= max_ticks) break;
+    }
+  }
+  if (threadIdx.x == 0) {
+    out[0] = t0 - t_begin; out[1] = r0 - r_begin; out[2] = lo; out[3] = hi; out[4] = nwin;
+  }
+}
+
+}  // namespace
+
+extern "C" int lg_contention_probe(float* dst, const float* src, long long n, int workgroups, int threads, int passes,
+                                   void* stream) {
+  LG_CHECK_ARG(dst && src && n >= 4 && n % 4 == 0, "lg_contention_probe: n must be a positive multiple of 4");
+  LG_CHECK_ARG(workgroups > 0 && workgroups <= 4096 && (threads == 256 || threads == 512) && passes > 0 && passes <= 64,
+               "lg_contention_probe: %d workgroups x %d threads x %d passes", workgroups, threads, passes);
+  hipLaunchKernelGGL(contention_kernel, dim3(workgroups), dim3(threads), 0, (hipStream_t)stream, dst, src, n / 4, passes);
+  LG_CHECK_LAUNCH("lg_contention_probe");
+  return LG_OK;
+}
+
+extern "C" int lg_clock_probe(unsigned long long* out5, const int* stop_flag, long long max_ms, void* stream) {
+  LG_CHECK_ARG(out5 && stop_flag && max_ms > 0 && max_ms <= 60000, "lg_clock_probe: bad args (max_ms in 1..60000)");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out5, stop_flag,
+                     (unsigned long long)max_ms * 100000ull, 100000u);
+  LG_CHECK_LAUNCH("lg_clock_probe");
+  return LG_OK;
+}

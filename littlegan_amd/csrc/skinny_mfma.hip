@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void dense_wgrad_mfma_kernel(const float* __re
 
 bool skinny_on() {
   static int on = -1;
-  if (on < 0) on = getenv("LG_NO_SKINNY_MFMA") ? 0 : 1;
+  if (on < 0) on = lg_env_flag("LG_NO_SKINNY_MFMA") ? 0 : 1;
   return on == 1;
 }
 

@@ -253,18 +253,7 @@ __global__ __launch_bounds__(512) void wgrad_at_kernel(const WgAtParams p) {
   }
 }
 
-inline int at_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      hipDeviceProp_t pr;
-      if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
-    }
-  }
-  return cus;
-}
+inline int at_cus() { return lg_grid_cus(); }   // CUs the persistent grid may fill (runtime.hip)
 
 // 0: not applicable, else the strip width (32 or 16)
 inline int at_shape(int Hm, int Wm, int cb, int cs) {
@@ -301,7 +290,7 @@ extern "C" size_t lg_wgrad_at_workspace_bytes(int B, int Hm, int Wm, int cb, int
 extern "C" int lg_wgrad_at_try(const void* big16, const void* small16, void* workspace, size_t ws_bytes, int B, int Hm, int Wm,
                                int cb, int cs, int* nsplit_out, void* stream) {
   static int off = -1;
-  if (off < 0) off = getenv("LG_NO_WGAT") ? 1 : 0;
+  if (off < 0) off = lg_env_flag("LG_NO_WGAT") ? 1 : 0;
   const int sw = at_shape(Hm, Wm, cb, cs);
   if (off || !sw || (sw == 8 && (B & 1)) || !big16 || !small16 || !nsplit_out) return LG_ERR_UNSUPPORTED;
   WgAtParams p{};

@@ -187,18 +187,7 @@ __global__ __launch_bounds__(512) void wgrad_at32_kernel(const Wg32Params p) {
   }
 }
 
-inline int at32_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      hipDeviceProp_t pr;
-      if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
-    }
-  }
-  return cus;
-}
+inline int at32_cus() { return lg_grid_cus(); }   // CUs the persistent grid may fill (runtime.hip)
 
 // 0: not applicable, else the strip width (16: 16 x 4 strips; 8: whole 8-column maps, 8 rows)
 inline int at32_shape(int Hm, int Wm, int cb, int cs) {
@@ -234,7 +223,7 @@ extern "C" size_t lg_wgrad_at32_workspace_bytes(int B, int Hm, int Wm, int cb, i
 extern "C" int lg_wgrad_at32_try(const float* big, const float* small, void* workspace, size_t ws_bytes, int B, int Hm, int Wm,
                                  int cb, int cs, int* nsplit_out, void* stream) {
   static int off = -1;
-  if (off < 0) off = getenv("LG_NO_WGAT32") ? 1 : 0;
+  if (off < 0) off = lg_env_flag("LG_NO_WGAT32") ? 1 : 0;
   const int sw = at32_shape(Hm, Wm, cb, cs);
   if (off || !sw || !big || !small || !nsplit_out) return LG_ERR_UNSUPPORTED;
   if ((long long)B * 4 * Hm * Wm * cb >= (1ll << 31) || (long long)B * Hm * Wm * cs >= (1ll << 31)) return LG_ERR_UNSUPPORTED;

@@ -450,7 +450,7 @@ extern "C" int lg_conv_wgrad_m16(const float* big, const void* big16, const floa
   LG_CHECK_ARG(B > 0 && Hm > 0 && Wm > 0 && cs % 32 == 0 && (cb == 3 || cb % 32 == 0),
                "lg_conv_wgrad: bad shape B=%d Hm=%d Wm=%d cb=%d cs=%d", B, Hm, Wm, cb, cs);
   LG_CHECK_ARG(ws_bytes >= lg_wgrad_workspace_bytes(B, Hm, Wm, cb, cs, dtype), "lg_conv_wgrad: workspace too small");
-  if (cb == 3 && !getenv("LG_NO_N3")) {  // all-taps 3-channel kernel (n3_kernels.hip) where its tiling applies
+  if (cb == 3 && !lg_env_flag("LG_NO_N3")) {  // all-taps 3-channel kernel (n3_kernels.hip) where its tiling applies
     const int rc = lg_n3_wgrad_try(big, small, dtype == LG_DT_BF16 ? small16 : nullptr, dw, workspace, ws_bytes, B, Hm, Wm,
                                    cs, pstride, ppad, accumulate, stream);
     if (rc != LG_ERR_UNSUPPORTED) return rc;

@@ -65,6 +65,7 @@ class EagerTrainer:
                           for m, (_, b1, b2) in self.opt_cfg.items()}
         self.losses = {k: torch.zeros(1, dtype=torch.float32, device=self.device) for k in ("gen", "disc", "adj")}
         self.sync = GradSync(self.device)
+        self.adam_order = ("D", "G", "A")   # = the launch order of the all-reduces (see train_step_from_inputs)
         self.global_epoch = 1
         self._input_step = 0  # counter window of the device-side step inputs (draw_step_inputs); part of the checkpoint
         self.rank, self.world = _dist_rank_world()
@@ -147,10 +148,16 @@ class EagerTrainer:
             A.backward_own(ctx_a, dpre_a)
             self.sync.launch("A", self.store, *self.store.model_range("A"))
 
-        # ---- optimizer applies, order A, D, G (eager_trainer.py:164-168); D-grads clipped after all-reduce
-        self.sync.wait_all()
+        # ---- optimizer applies.  The reference applies A, D, G (eager_trainer.py:164-168); the three weight ranges, Adam
+        # slots and beta-power pairs are disjoint, so any order gives the same bits (tests/test_step_gpu.py::
+        # test_adam_order_is_immaterial, tests/test_dp_cpu.py).  Here: the order the all-reduces were launched in, each set
+        # waited for on its own right before its Adam — D and G are applied while A's all-reduce (launched last) is on the
+        # wire.  D-grads are clipped after the all-reduce, inside the Adam kernel.
         gscale = 1.0 / self.sync.world_size
-        for m in (("A",) if run_adj else ()) + ("D", "G"):
+        for m in self.adam_order:
+            if m == "A" and not run_adj:
+                continue
+            self.sync.wait(m)
             lo, hi = train_weight_range(a, m, batch_no)
             s, e = self.store.model_range(m, lo, hi)
             lr, b1, b2 = self.opt_cfg[m]
@@ -159,6 +166,7 @@ class EagerTrainer:
             ops.clip_adam_update(st.flat[s:e], st.grad[s:e], st.m[s:e], st.v[s:e], self.opt_state[m], lr, b1, b2,
                                  ADAM_EPS, clip, gscale)
             ops.adam_advance(self.opt_state[m], b1, b2)
+        self.sync.wait_all()
         self.store.bump()
         return (fake, adj_image, self.losses["gen"], self.losses["disc"], self.losses["adj"] if run_adj else None)
 

@@ -70,6 +70,35 @@ def test_partition_schedule_mirror():
     assert train_weight_range(a, "G", 5) == (0, 22)
 
 
+def test_adam_sets_are_disjoint_so_their_order_is_immaterial():
+    """The trainer applies the three optimizers in all-reduce launch order (D, G, A: each set right after ITS wait), the
+    reference in the order A, D, G (eager_trainer.py:164-168).  The oracle's own TF-v1 Adam on the flat store's ranges: the
+    three weight / slot ranges never overlap and each optimizer owns its beta powers, so both orders give identical bits."""
+    cfg = O.Cfg(**CFG)
+    store, g, d, adj = _store(cfg)
+    spans = {m: store.model_range(m) for m in "GDA"}
+    for a_, b_ in (("G", "D"), ("D", "A"), ("G", "A")):
+        assert spans[a_][1] <= spans[b_][0] or spans[b_][1] <= spans[a_][0]
+    rng = np.random.default_rng(3)
+    n = store.flat.numel()
+    w0, grad = rng.standard_normal(n), rng.standard_normal(n)
+    results = []
+    for order in (("A", "D", "G"), ("D", "G", "A")):
+        w = [w0.copy()]   # ONE flat weight vector, the optimizers write their own slices
+        opts = {"G": O.AdamState(cfg.lr, cfg.beta_1, cfg.beta_2, 1), "D": O.AdamState(cfg.lr, cfg.beta_1, cfg.beta_2, 1),
+                "A": O.AdamState(cfg.lr, 0.9, 0.999, 1)}
+        for step in range(2):
+            for m in order:
+                s, e = spans[m]
+                part = [w[0][s:e]]
+                opts[m].apply(part, [0], [np.clip(grad[s:e], -cfg.clip_range, cfg.clip_range) if m == "D" else grad[s:e]])
+                w[0][s:e] = part[0]
+        results.append((w[0].copy(), [(o.b1p, o.b2p) for o in opts.values()], [o.m[0].copy() for o in opts.values()]))
+    assert np.array_equal(results[0][0], results[1][0]) and results[0][1] == results[1][1]
+    assert all(np.array_equal(x, y) for x, y in zip(results[0][2], results[1][2]))
+    assert not np.array_equal(results[0][0], w0)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -101,7 +130,9 @@ def _worker(rank, world, port, out_q, batch_no=11):
         a = _args(cfg)
         for m in ("D", "G", "A"):  # launch order of the step: D, G, A; a partition step exchanges its trained range only
             sync.launch(m, store, *store.model_range(m, *train_weight_range(a, m, batch_no)))
-        sync.wait_all()
+        for m in ("D", "G", "A"):   # the step waits per set, right before that set's Adam (eager_trainer.py of this package)
+            sync.wait(m)
+        assert not sync._pending
         if rank == 0:
             out_q.put(store.grad.numpy().copy())
     finally:

@@ -516,6 +516,65 @@ def test_whole_f32_step_at_c2_batch():
                 assert r < 5e-3, (m, i, r)   # (f32: a LeakyReLU pre-activation at rounding distance from 0 may flip between the two groupings)
 
 
+def test_whole_f32_step_at_c3_batch():
+    """The C3 step (128x128, B = 256, G + D + Adjuster, b = 11) on the EXACT-f32 path — the configuration `bench.py --workload c3
+    --dtype f32` times, i.e. the throughput number that goes with the north star's 1e-4 loss tolerance.  Fake and adjusted rows
+    against the fp64 oracle on sampled rows (2e-5), the three losses against the fp64 oracle's losses of the same step on a
+    32-image slice run through BOTH implementations (kernel vs oracle: 2e-5 relative, the bound of tests/test_step_gpu.py), and
+    losses / every gradient tensor of the big step against the mean of the same step on 32-image slices (no launch of the 2B = 512
+    grids mixes or drops samples).  Reference: eager_trainer.py:133-168."""
+    from test_step_gpu import build, dev_inputs, f32_round, perturbed
+    B, chunk = 256, 32
+    cfg = O.Cfg(init_dim=8, cond_dim=40, batch_size=B)
+    W = perturbed(cfg, 7)
+    tr = build(cfg, W, "f32")
+    inp = f32_round(O.make_inputs(cfg, B, seed=29))
+    d_in = dev_inputs(inp)
+    fake, adj, lg, ld, la = tr.train_step_from_inputs(11, d_in)
+    torch.cuda.synchronize()
+    grads = tr.store.grad.clone()
+    losses = np.array([lg.item(), ld.item(), la.item()])
+    assert np.isfinite(losses).all() and torch.isfinite(grads).all()
+    idx = [0, B // 2 - 1, B - 1]
+    cfg_s = O.Cfg(init_dim=8, cond_dim=40, batch_size=len(idx))
+    ref, _ = O.generator_fwd(cfg_s, W["G"], inp["noise"][idx], inp["real_cond_2"][idx])
+    got = _f64(fake[idx])
+    assert np.abs(got - ref).max() < 2e-5
+    a_img = np.concatenate([inp["real_image_1"][idx], got], 0)
+    a_cond = (np.concatenate([inp["real_cond_2"][idx], inp["real_cond_1"][idx]], 0) + 1.0) * 0.5
+    a_ref, _ = O.adjuster_fwd(O.Cfg(init_dim=8, cond_dim=40, batch_size=2 * len(idx)), W, a_img, a_cond)
+    a_got = np.concatenate([_f64(adj[idx]), _f64(adj[[B + i for i in idx]])], 0)
+    assert np.abs(a_got - a_ref).max() < 4e-5
+    cfg_c = O.Cfg(init_dim=8, cond_dim=40, batch_size=chunk)
+    trc = build(cfg_c, W, "f32")
+    trc.opt_cfg = {m: (0.0, b1, b2) for m, (_, b1, b2) in trc.opt_cfg.items()}
+    acc = torch.zeros_like(grads, dtype=torch.float64)
+    lacc = np.zeros(3)
+    n = B // chunk
+    for k in range(n):
+        sl = {key: v[k * chunk:(k + 1) * chunk].contiguous() for key, v in d_in.items()}
+        fk, ak, lgk, ldk, lak = trc.train_step_from_inputs(11, sl)
+        assert float((fk - fake[k * chunk:(k + 1) * chunk]).abs().max()) < 2e-5
+        if k == 0:   # the three loss scalars of one slice against the fp64 oracle (the stated tolerance: 2e-5 < 1e-4 relative)
+            o = O.step_gradients(cfg_c, W, 11, {key: v[:chunk] for key, v in inp.items()})
+            for gotl, key in ((lgk, "gen_loss"), (ldk, "disc_loss"), (lak, "adj_loss")):
+                assert abs(gotl.item() - o[key]) < 2e-5 * abs(o[key]), (key, gotl.item(), o[key])
+        acc += trc.store.grad.double()
+        lacc += np.array([lgk.item(), ldk.item(), lak.item()])
+    assert np.abs(lacc / n - losses).max() < 4e-6 * np.abs(losses).max(), (lacc / n, losses)
+    mean = acc / n
+    gmax = float(grads.abs().max())
+    numel = {m: [t[5] for t in tr.store.index if t[0] == m] for m in "DGA"}
+    for m in "DGA":
+        for i, (s, e) in enumerate(tr.store.ranges[m]):
+            a, b = grads[s:e].double(), mean[s:e]
+            if numel[m][i] == 1:
+                assert abs(float(a[0]) - float(b[0])) <= 2e-4 * gmax, (m, i)
+            else:
+                r = float((a - b).pow(2).mean().sqrt()) / (float(b.pow(2).mean().sqrt()) + 1e-30)
+                assert r < 5e-3, (m, i, r)
+
+
 @pytest.mark.parametrize("layer", ["enc.conv2", "enc.conv3"])
 def test_normalising_down_conv_at_the_adjuster_batch(ops, layer):
     """lg_conv2d_s2_fwd_stats_zn at the size the step launches it: D on the Adjuster's output, 2B = 512 images

@@ -192,6 +192,28 @@ def test_partition_and_beta_powers():
     assert tr.opt_state["G"].tolist() == pytest.approx([0.25, 0.81]) and tr.opt_state["A"].tolist() == pytest.approx([0.9, 0.999])
 
 
+@pytest.mark.parametrize("mfma", ["f32", "bf16"])
+def test_adam_order_is_immaterial(mfma):
+    """The reference applies A, D, G (eager_trainer.py:164-168); the trainer applies D, G, A (each set right after ITS
+    all-reduce, littlegan_amd/dist.py).  The three weight ranges, Adam slots and beta-power pairs are disjoint: weights,
+    slots and beta powers after three steps (full, full, partition) are bit-identical in both orders."""
+    cfg = O.Cfg(init_dim=2, conv_filter=(32, 32, 32, 32, 32), cond_dim=3, noise_dim=5, batch_size=2)
+    W = perturbed(cfg, 4)
+    inp = dev_inputs(f32_round(O.make_inputs(cfg, 2, seed=9)))
+    got = []
+    for order in (("A", "D", "G"), ("D", "G", "A")):
+        tr = build(cfg, W, mfma)
+        tr.adam_order = order
+        for b in (11, 12, 15):
+            tr.train_step_from_inputs(b, inp)
+        torch.cuda.synchronize()
+        got.append((tr.store.flat.clone(), tr.store.m.clone(), tr.store.v.clone(),
+                    torch.cat([tr.opt_state[m] for m in "GDA"]).clone()))
+    for x, y in zip(*got):
+        assert torch.equal(x, y)
+    assert not torch.equal(got[0][0], torch.cat([torch.zeros_like(got[0][0])]))
+
+
 def test_golden_fixture_f32():
     from tests.golden.make_golden import CFG, STEPS
     g = np.load(GOLD)
