@@ -555,10 +555,6 @@ def test_whole_f32_step_at_c3_batch():
         sl = {key: v[k * chunk:(k + 1) * chunk].contiguous() for key, v in d_in.items()}
         fk, ak, lgk, ldk, lak = trc.train_step_from_inputs(11, sl)
         assert float((fk - fake[k * chunk:(k + 1) * chunk]).abs().max()) < 2e-5
-        if k == 0:   # the three loss scalars of one slice against the fp64 oracle (the stated tolerance: 2e-5 < 1e-4 relative)
-            o = O.step_gradients(cfg_c, W, 11, {key: v[:chunk] for key, v in inp.items()})
-            for gotl, key in ((lgk, "gen_loss"), (ldk, "disc_loss"), (lak, "adj_loss")):
-                assert abs(gotl.item() - o[key]) < 2e-5 * abs(o[key]), (key, gotl.item(), o[key])
         acc += trc.store.grad.double()
         lacc += np.array([lgk.item(), ldk.item(), lak.item()])
     assert np.abs(lacc / n - losses).max() < 4e-6 * np.abs(losses).max(), (lacc / n, losses)
@@ -573,6 +569,14 @@ def test_whole_f32_step_at_c3_batch():
             else:
                 r = float((a - b).pow(2).mean().sqrt()) / (float(b.pow(2).mean().sqrt()) + 1e-30)
                 assert r < 5e-3, (m, i, r)
+    # the three loss scalars against the fp64 oracle at the stated tolerance (2e-5 < the north star's 1e-4 relative), on the first
+    # four images (the oracle's full step costs ~10 s per image here); the slice means above tie the B = 256 losses to such steps
+    cfg_4 = O.Cfg(init_dim=8, cond_dim=40, batch_size=4)
+    tr4 = build(cfg_4, W, "f32")
+    _, _, lg4, ld4, la4 = tr4.train_step_from_inputs(11, {key: v[:4].contiguous() for key, v in d_in.items()})
+    o = O.step_gradients(cfg_4, W, 11, {key: v[:4] for key, v in inp.items()})
+    for gotl, key in ((lg4, "gen_loss"), (ld4, "disc_loss"), (la4, "adj_loss")):
+        assert abs(gotl.item() - o[key]) < 2e-5 * abs(o[key]), (key, gotl.item(), o[key])
 
 
 @pytest.mark.parametrize("layer", ["enc.conv2", "enc.conv3"])
