@@ -46,8 +46,14 @@ def synthetic_inputs(args, device, rank):
     B, H = args.batch_size, args.init_dim * 16
     img = lambda: (torch.rand(B, H, H, 3, generator=g) * 2 - 1).to(device)
     cond = lambda: (0.96 * (2.0 * torch.randint(0, 2, (B, args.cond_dim), generator=g).float() - 1.0) + 0.02).to(device)
-    return dict(real_image_1=img(), real_cond_1=cond(), real_image_2=img(), real_cond_2=cond(),
-                noise=torch.randn(B, args.noise_dim, generator=g).to(device), new_image=img())
+    out = dict(real_image_1=img(), real_cond_1=cond(), real_image_2=img(), real_cond_2=cond(),
+               noise=torch.randn(B, args.noise_dim, generator=g).to(device))
+    # new_image is resident as the first half of the discriminator's [new_image ; fake] input batch — where the training loop's
+    # augmentation kernel writes it (EagerTrainer._train_step); the Generator writes `fake` into the second half every step
+    d_in = torch.empty(2 * B, H, H, 3, dtype=torch.float32, device=device)
+    d_in[:B].copy_(img())
+    out["disc_input"], out["new_image"] = d_in, d_in[:B]
+    return out
 
 
 def _cpu_time_step(cfg_kw, Bc, min_steps, budget_s, max_steps=20):
@@ -249,27 +255,45 @@ def main():
     b_next = b0 + a.warmup + a.steps + 100
     clock = None
     if world == 1 and not profiled:
-        # shader clock HELD under this step: one probe wave beside 20 steps (side stream; d s_memtime / d s_memrealtime in
-        # 1-ms windows, lg_clock_probe).  The persistent kernels leave ONE CU's worth of blocks free meanwhile so that the
-        # resident probe wave displaces none of them; the leg's own ms/step is printed beside the clock.
+        # Shader clock HELD under this step, two ways (both after the timed region; d s_memtime / d s_memrealtime x 100 MHz):
+        #  (a) one probe wave resident on a side stream beside 20 further steps, 1-ms windows (lg_clock_probe; it ends when
+        #      lg_clock_stop raises its flag or when its time budget — the leg's expected length — is spent);
+        #  (b) a 20-us sampling wave on the COMPUTE stream right behind every conv-class launch of 5 further steps
+        #      (lg_clock_sample): the clock at those points of the step (the power controller moves it on a millisecond scale).
         from littlegan_amd import _lib as lib
+        L_ = lib.load()
+        ms_ref = dt / a.steps * 1e3
         out5 = torch.zeros(5, dtype=torch.int64, device=device)
+        series = torch.zeros(2048, dtype=torch.int32, device=device)
         flag = torch.zeros(1, dtype=torch.int32, device=device)
         side = torch.cuda.Stream(device=device)
-        was = tr.sync.reserved_cus
-        tr.sync.reserve_cus(max(was, 1))
         timed_steps(5, b_next)
         with torch.cuda.stream(side):
-            lib.check(lib.load().lg_clock_probe(out5.data_ptr(), flag.data_ptr(), 20000, side.cuda_stream), "lg_clock_probe")
+            lib.check(L_.lg_clock_probe(out5.data_ptr(), flag.data_ptr(), int(20 * ms_ref * 1.5) + 50, series.data_ptr(), series.numel(),
+                                        side.cuda_stream), "lg_clock_probe")
         ms_clk = timed_steps(20, b_next + 5)
-        flag.fill_(1)
+        lib.check(L_.lg_clock_stop(flag.data_ptr(), torch.cuda.current_stream().cuda_stream), "lg_clock_stop")
         torch.cuda.synchronize()
-        tr.sync.reserve_cus(was)
         o = out5.tolist()
-        if o[1] > 0:
-            clock = {"mean_mhz": round(o[0] / o[1] * 100.0, 1), "min_window_mhz": round(o[2] / 1e3, 1), "max_window_mhz": round(o[3] / 1e3, 1),
+        if o[1] > 0 and o[4] > 0:
+            w = sorted(series[:min(int(o[4]), series.numel())].tolist())
+            pick = lambda q: round(w[min(len(w) - 1, int(q * len(w)))] / 1e3, 1)
+            clock = {"mean_mhz": round(o[0] / o[1] * 100.0, 1), "p10_mhz": pick(0.10), "median_mhz": pick(0.50), "p90_mhz": pick(0.90),
+                     "min_window_mhz": round(o[2] / 1e3, 1), "max_window_mhz": round(o[3] / 1e3, 1),
                      "windows_1ms": o[4], "leg_ms_per_step": round(ms_clk, 3),
-                     "method": "d s_memtime / d s_memrealtime x 100 MHz of one probe wave resident beside 20 further steps (after the timed region)"}
+                     "method": "d s_memtime / d s_memrealtime x 100 MHz of one probe wave resident on a side stream beside 20 further steps (after the timed region)"}
+        out3 = torch.zeros(3, dtype=torch.int64, device=device)
+        ops.Profile.start()
+        ops.Profile.after_conv = lambda: lib.check(L_.lg_clock_sample(out3.data_ptr(), 20, torch.cuda.current_stream().cuda_stream), "lg_clock_sample")
+        try:
+            ms_smp = timed_steps(5, b_next + 30)
+        finally:
+            ops.Profile.after_conv = None
+            ops.Profile.stop()
+        o3 = out3.tolist()
+        if o3[1] > 0:
+            clock = dict(clock or {}, in_stream_samples={"mean_mhz": round(o3[0] / o3[1] * 100.0, 1), "samples": o3[2], "leg_ms_per_step": round(ms_smp, 3),
+                                                          "method": "20-us sampling wave on the compute stream behind every conv-class launch of 5 further steps"})
         b_next += 100
     contention = None
     ks = [int(k) for k in a.dp_contention.split(",")] if a.dp_contention else ([32] if (world == 1 and a.workload == "c3" and args.mfma_dtype == "bf16" and not profiled) else [])

@@ -41,6 +41,8 @@ const char* lg_last_error(void);
 /* Name of the kernel template the calling thread's last conv / weight-gradient entry point launched ("" if none yet): a
  * static string such as "conv_up3_kernel<64,32>".  Measurement aid (bench.py's per-kernel roofline); no reference counterpart. */
 const char* lg_last_kernel(void);
+/* Resets that name to "": the name is sticky, so a timing harness clears it before a call whose launch path may name no kernel. */
+int lg_clear_kernel(void);
 
 /* ---- weight packing (once per layer per step; weights change every step) ------------------------
  * master kernel w[5][5][cb][cs] -> MFMA B-operand images in `dtype` (down pack + up pack). */
@@ -209,6 +211,12 @@ int lg_dense_wgrad(const float* x, const float* dy, float* dw, float* db, int B,
                    void* stream);
 /* dx[B][K] = dy[B][N] @ w[K][N]^T (not needed by the step's tapes: the dense inputs are noise / conditions) */
 int lg_dense_dgrad(const float* dy, const float* w, float* dx, int B, int K, int N, void* stream);
+/* out[B][ka+kc] = [a | c]: keras.layers.concatenate([input_noise, input_cond], axis=-1) in front of the Generator's
+   dense layer, model.py:97-98 */
+int lg_concat_cols(const float* a, int ka, const float* c, int kc, float* out, int B, void* stream);
+/* t[2B][c] = tf.concat([first, second], 0), u = (t + 1) * 0.5: the Adjuster's target / input conditions,
+   eager_trainer.py:153-154 (first = real_cond_2, second = real_cond_1) */
+int lg_adj_conditions(const float* first, const float* second, float* t, float* u, int B, int c, void* stream);
 /* p[B][1+c] = sigmoid(x[B][K] @ [wpr | wc] + [bpr | bc]) : column 0 = output_pr, 1.. = output_cond */
 size_t lg_heads_fwd_workspace_bytes(int B, int K, int c);
 int lg_heads_fwd(const float* x, const float* wpr, const float* bpr, const float* wc, const float* bc, float* p,
@@ -272,9 +280,14 @@ int lg_grid_cus(void);
  * stream dst = 0.5 dst + src over n floats (n % 4 == 0), `passes` times — what a ring step does to the CUs it occupies */
 int lg_contention_probe(float* dst, const float* src, long long n, int workgroups, int threads, int passes, void* stream);
 /* one wave beside the step (launch it on a SIDE stream): shader clock held, in 1-ms windows, until *stop_flag != 0 (device
- * memory) or max_ms have passed.  out5 = {d s_memtime, d s_memrealtime (100 MHz ticks), min window kHz, max window kHz,
- * number of windows}: mean clock = out5[0] / out5[1] x 100 MHz */
-int lg_clock_probe(unsigned long long* out5, const int* stop_flag, long long max_ms, void* stream);
+ * memory, raised by lg_clock_stop) or max_ms have passed — an exit the wave always reaches.  out5 = {sum d s_memtime,
+ * sum d s_memrealtime (100 MHz ticks), min window kHz, max window kHz, number of windows}: mean clock = out5[0] / out5[1] x 100 MHz;
+ * series (optional, series_cap entries): kHz per window */
+int lg_clock_probe(unsigned long long* out5, const int* stop_flag, long long max_ms, unsigned* series, int series_cap, void* stream);
+int lg_clock_stop(int* stop_flag, void* stream);
+/* one wave on the COMPUTE stream that spins spin_us microseconds behind the previous kernel and ADDS {d s_memtime, d s_memrealtime, 1}
+ * to out3: the clock the chip holds at that point of the step */
+int lg_clock_sample(unsigned long long* out3, int spin_us, void* stream);
 
 #ifdef __cplusplus
 }

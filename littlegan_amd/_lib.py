@@ -60,6 +60,7 @@ SIGNATURES = {
     "lg_instnorm_bwd_db_workspace_bytes": (Z, [I, L, I]),
     "lg_instnorm_leaky_bwd_db": (I, [P, P, P, I, P, P, P, P, P, I, P, Z, I, L, I, I, F, I, P]),
     "lg_last_kernel": (C.c_char_p, []),
+    "lg_clear_kernel": (I, []),
     "lg_instnorm_leaky_apply_z16": (I, [P, P, P, I, P, P, I, L, I, I, F, P]),
     "lg_instnorm_leaky_apply_z16_p": (I, [P, P, I, P, P, P, P, I, P, P, I, L, I, F, P]),
     "lg_instnorm_leaky_bwd_z16": (I, [P, P, P, I, P, P, P, P, P, I, P, Z, I, L, I, I, F, I, P]),
@@ -70,6 +71,8 @@ SIGNATURES = {
     "lg_dense_fwd": (I, [P, P, P, P, I, I, I, P]),
     "lg_dense_wgrad": (I, [P, P, P, P, I, I, I, I, P]),
     "lg_dense_dgrad": (I, [P, P, P, I, I, I, P]),
+    "lg_concat_cols": (I, [P, I, P, I, P, I, P]),
+    "lg_adj_conditions": (I, [P, P, P, P, I, I, P]),
     "lg_heads_fwd_workspace_bytes": (Z, [I, I, I]),
     "lg_heads_fwd": (I, [P, P, P, P, P, P, P, Z, I, I, I, P]),
     "lg_heads_dgrad": (I, [P, P, P, P, I, I, I, P]),
@@ -91,7 +94,9 @@ SIGNATURES = {
     "lg_set_reserved_cus": (I, [I]),
     "lg_grid_cus": (I, []),
     "lg_contention_probe": (I, [P, P, L, I, I, I, P]),
-    "lg_clock_probe": (I, [P, P, L, P]),
+    "lg_clock_probe": (I, [P, P, L, P, I, P]),
+    "lg_clock_stop": (I, [P, P]),
+    "lg_clock_sample": (I, [P, I, P]),
     "lg_augment_drawn": (I, [P, P, I, I, I, F, F, F, F, F, L, L, L, P, Z, P]),
 }
 

@@ -32,7 +32,10 @@ def build(force=False, verbose=True, variant=None):
     if not variant and os.environ.get("LG_EXTRA_FLAGS"):
         raise SystemExit("LG_EXTRA_FLAGS needs --variant NAME: ablation builds never replace the product library")
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(HERE, "lg_common.h"), os.path.join(os.path.dirname(PKG), "include", "littlegan_hip.h")]
+    common_h, public_h = os.path.join(HERE, "lg_common.h"), os.path.join(os.path.dirname(PKG), "include", "littlegan_hip.h")
+
+    def hdrs_of(path):   # the public header is a dependency of the sources that include it (capi.hip, runtime.hip), not of every kernel file
+        return [common_h] + ([public_h] if "littlegan_hip.h" in open(path).read() else [])
 
     # LG_EXTRA_FLAGS carries the ablation macros of scripts/probe/*.sh ("results wrong, timing only"): the flag set an object
     # was built with is recorded beside it, and an object (hence the library) built with OTHER flags is stale — a probe build
@@ -54,7 +57,7 @@ def build(force=False, verbose=True, variant=None):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         fl = o + ".flags"
         same_flags = os.path.exists(fl) and open(fl).read() == flag_line
-        if force or not same_flags or _stale(o, [s] + hdrs):
+        if force or not same_flags or _stale(o, [s] + hdrs_of(s)):
             cmd = [hipcc] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)

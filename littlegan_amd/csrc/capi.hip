@@ -17,6 +17,7 @@ extern "C" const char* lg_last_error(void) { return g_err; }
 static thread_local const char* g_kernel = "";
 extern "C" void lg_note_kernel(const char* name) { g_kernel = name ? name : ""; }
 extern "C" const char* lg_last_kernel(void) { return g_kernel; }
+extern "C" int lg_clear_kernel(void) { g_kernel = ""; return LG_OK; }
 extern "C" int lg_abi_version(void) { return LG_ABI_VERSION; }
 
 extern "C" int lg_conv_igemm(int mode, int dtype, const float* src, const void* wpack, const float* bias, float* out,

@@ -118,7 +118,47 @@ __global__ __launch_bounds__(256) void dense_dgrad_kernel(const float* __restric
   if (lane == 0) dx[(long long)b * K + k] = s;
 }
 
+// ---------------------------------------------------------------- dense inputs
+// out[b] = [a[b] | c[b]]: the Generator's dense input `concat([noise, cond], -1)` (model.py:97-98)
+__global__ __launch_bounds__(256) void concat_cols_kernel(const float* __restrict__ a, int ka, const float* __restrict__ c, int kc,
+                                                          float* __restrict__ out, long long total) {
+  const int k = ka + kc;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long b = i / k;
+    const int j = (int)(i - b * k);
+    out[i] = j < ka ? a[b * ka + j] : c[b * kc + (j - ka)];
+  }
+}
+
+// t = [first ; second] (rows), u = (t + 1) * 0.5: the Adjuster's target and input conditions (eager_trainer.py:153-154)
+__global__ __launch_bounds__(256) void adj_conditions_kernel(const float* __restrict__ first, const float* __restrict__ second,
+                                                             float* __restrict__ t, float* __restrict__ u, long long half) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < 2 * half; i += (long long)gridDim.x * 256) {
+    const float v = i < half ? first[i] : second[i - half];
+    t[i] = v;
+    u[i] = (v + 1.0f) * 0.5f;
+  }
+}
+
 }  // namespace
+
+extern "C" int lg_concat_cols(const float* a, int ka, const float* c, int kc, float* out, int B, void* stream) {
+  LG_CHECK_ARG(a && c && out && B > 0 && ka > 0 && kc > 0, "lg_concat_cols: bad arguments B=%d ka=%d kc=%d", B, ka, kc);
+  const long long total = (long long)B * (ka + kc);
+  const long long nb = (total + 255) / 256;
+  hipLaunchKernelGGL(concat_cols_kernel, dim3((int)(nb < 1024 ? nb : 1024)), dim3(256), 0, (hipStream_t)stream, a, ka, c, kc, out, total);
+  LG_CHECK_LAUNCH("lg_concat_cols");
+  return LG_OK;
+}
+
+extern "C" int lg_adj_conditions(const float* first, const float* second, float* t, float* u, int B, int c, void* stream) {
+  LG_CHECK_ARG(first && second && t && u && B > 0 && c > 0, "lg_adj_conditions: bad arguments B=%d c=%d", B, c);
+  const long long half = (long long)B * c;
+  const long long nb = (2 * half + 255) / 256;
+  hipLaunchKernelGGL(adj_conditions_kernel, dim3((int)(nb < 1024 ? nb : 1024)), dim3(256), 0, (hipStream_t)stream, first, second, t, u, half);
+  LG_CHECK_LAUNCH("lg_adj_conditions");
+  return LG_OK;
+}
 
 extern "C" int lg_dense_fwd_mfma_try(const float* x, const float* w, const float* bias, float* y, int B, int K, int N,
                                      void* stream);

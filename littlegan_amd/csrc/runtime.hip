@@ -70,26 +70,52 @@ __global__ __launch_bounds__(512) void contention_kernel(float* __restrict__ dst
 }
 
 __global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* __restrict__ out, const int* stop,
-                                                         unsigned long long max_ticks, unsigned window_ticks) {
-  // one wave; lane 0 writes.  out: [0] d memtime, [1] d realtime (100 MHz), [2] min window kHz, [3] max window kHz, [4] windows
+                                                         unsigned long long max_ticks, unsigned window_ticks,
+                                                         unsigned* __restrict__ series, int series_cap) {
+  // one wave; lane 0 writes.  out: [0] d memtime, [1] d realtime (100 MHz), [2] min window kHz, [3] max window kHz, [4] windows;
+  // series[w] (optional) = kHz of window w, so that the caller can cut the windows that overlap ITS load out of the whole run.
+  // A window in which the cycle counter does not advance monotonically (seen once per run on this chip) is dropped.
   const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime(), t_begin = __builtin_amdgcn_s_memtime();
-  unsigned long long r0 = r_begin, t0 = t_begin, lo = ~0ull, hi = 0, nwin = 0;
+  unsigned long long r0 = r_begin, t0 = t_begin, lo = ~0ull, hi = 0, nwin = 0, tsum = 0, rsum = 0;
   for (;;) {
     __builtin_amdgcn_s_sleep(64);
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     if (r1 - r0 >= window_ticks) {
       const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-      const unsigned long long khz = (t1 - t0) * 100000ull / (r1 - r0);   // cycles per 10-ns tick x 1e5 = kHz
-      lo = khz < lo ? khz : lo;
-      hi = khz > hi ? khz : hi;
-      ++nwin;
+      if (t1 > t0 && t1 - t0 < (r1 - r0) * 64ull) {   // < 6.4 GHz: a sane window
+        const unsigned long long khz = (t1 - t0) * 100000ull / (r1 - r0);   // cycles per 10-ns tick x 1e5 = kHz
+        lo = khz < lo ? khz : lo;
+        hi = khz > hi ? khz : hi;
+        tsum += t1 - t0; rsum += r1 - r0;
+        if (series && nwin < (unsigned long long)series_cap && threadIdx.x == 0) series[nwin] = (unsigned)khz;
+        ++nwin;
+      }
       r0 = r1; t0 = t1;
-      if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || r1 - r_begin >= max_ticks) break;
+      if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || r1 - r_begin >= max_ticks) break;
     }
   }
   if (threadIdx.x == 0) {
-    out[0] = t0 - t_begin; out[1] = r0 - r_begin; out[2] = lo; out[3] = hi; out[4] = nwin;
+    out[0] = tsum; out[1] = rsum; out[2] = lo; out[3] = hi; out[4] = nwin;
   }
+}
+
+__global__ void clock_stop_kernel(int* flag) {   // a store the resident probe wave's system-scope poll sees (no cached copy in an L2)
+  if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// One wave that spins for `spin_ticks` of the 100 MHz clock and reports d s_memtime / d s_memrealtime: launched on the COMPUTE
+// stream right behind a kernel, it reads the clock the chip holds at that point of the step (the power controller moves the
+// clock on a millisecond scale, the sample takes 10-20 us).  out2[0] += d memtime, out2[1] += d realtime (one lane, plain adds:
+// samples on one stream run in order).
+__global__ __launch_bounds__(64) void clock_sample_kernel(unsigned long long* __restrict__ out2, unsigned spin_ticks) {
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r1 = r0;
+  for (int i = 0; i < 100000 && r1 - r0 < spin_ticks; ++i) {   // bounded spin: every wave reaches the exit
+    __builtin_amdgcn_s_sleep(8);
+    r1 = __builtin_amdgcn_s_memrealtime();
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0 && t1 > t0) { out2[0] += t1 - t0; out2[1] += r1 - r0; out2[2] += 1; }
 }
 
 }  // namespace
@@ -104,10 +130,26 @@ extern "C" int lg_contention_probe(float* dst, const float* src, long long n, in
   return LG_OK;
 }
 
-extern "C" int lg_clock_probe(unsigned long long* out5, const int* stop_flag, long long max_ms, void* stream) {
+extern "C" int lg_clock_probe(unsigned long long* out5, const int* stop_flag, long long max_ms, unsigned* series, int series_cap,
+                              void* stream) {
   LG_CHECK_ARG(out5 && stop_flag && max_ms > 0 && max_ms <= 60000, "lg_clock_probe: bad args (max_ms in 1..60000)");
+  LG_CHECK_ARG(series_cap >= 0 && (series || series_cap == 0), "lg_clock_probe: series buffer / capacity mismatch");
   hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out5, stop_flag,
-                     (unsigned long long)max_ms * 100000ull, 100000u);
+                     (unsigned long long)max_ms * 100000ull, 100000u, series, series_cap);
   LG_CHECK_LAUNCH("lg_clock_probe");
+  return LG_OK;
+}
+
+extern "C" int lg_clock_sample(unsigned long long* out3, int spin_us, void* stream) {
+  LG_CHECK_ARG(out3 && spin_us > 0 && spin_us <= 1000, "lg_clock_sample: bad args (spin_us in 1..1000)");
+  hipLaunchKernelGGL(clock_sample_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out3, (unsigned)spin_us * 100u);
+  LG_CHECK_LAUNCH("lg_clock_sample");
+  return LG_OK;
+}
+
+extern "C" int lg_clock_stop(int* stop_flag, void* stream) {
+  LG_CHECK_ARG(stop_flag, "lg_clock_stop: null flag");
+  hipLaunchKernelGGL(clock_stop_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stop_flag);
+  LG_CHECK_LAUNCH("lg_clock_stop");
   return LG_OK;
 }

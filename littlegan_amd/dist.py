@@ -7,12 +7,13 @@ stream as soon as its tape's backward has been enqueued, overlapping the next ta
 The 1/world_size scale and the D-clip are applied afterwards inside the Adam kernel; the compute stream waits
 per SET (`wait(name)`) right before that set's Adam — D and G are applied while A's all-reduce is still on the wire.
 
-CU budget: RCCL's ring kernels need CUs at exactly the points `launch` fires, while the persistent conv kernels assume
-every one of their blocks is resident from the start.  `reserve_cus` (default RESERVED_CUS_DP under data parallelism)
-shrinks the persistent grids (lg_set_reserved_cus) so that the communication workgroups find free CUs instead of
-displacing a block into a serial tail.  `rehearse(K)` is the one-GPU rehearsal of that situation (bench.py
---dp-contention): instead of an all-reduce, `launch` puts K streaming read-add-write workgroups over a range of the same
-size on the side stream (lg_contention_probe)."""
+CU budget: RCCL's ring kernels need CUs at exactly the points `launch` fires, while the persistent conv kernels size their
+grids to every CU.  `reserve_cus(n)` shrinks the persistent grids (lg_set_reserved_cus) so that communication workgroups would
+find free CUs; `rehearse(K)` is the one-GPU rehearsal of the situation (bench.py --dp-contention): instead of an all-reduce,
+`launch` puts K streaming read-add-write workgroups over a range of the same size on the side stream (lg_contention_probe).
+MEASURED (round 4, one MI355X, C3 step 11.82 ms): K = 8 / 16 / 32 / 64 side workgroups cost +4.6 / +3.6 / +2.9 / +2.8 %
+with the grids at full size and +7.5 / +7.0 / +9.0 / +14.4 % with K CUs left free — a displaced persistent block is cheaper than a
+CU that idles for the whole step, so the default reservation under data parallelism is 0 (LG_RESERVED_CUS overrides)."""
 from __future__ import annotations
 
 import os
@@ -20,9 +21,9 @@ import os
 import torch
 import torch.distributed as dist
 
-# CUs left to the communication kernels when world > 1 (measured on the one-GPU rehearsal): RCCL's ring kernels
-# take one workgroup per channel; LG_RESERVED_CUS overrides.
-RESERVED_CUS_DP = 32
+# CUs left to the communication kernels when world > 1: 0 — measured on the one-GPU rehearsal (module docstring);
+# LG_RESERVED_CUS overrides.
+RESERVED_CUS_DP = 0
 
 
 class GradSync:

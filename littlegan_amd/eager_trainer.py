@@ -97,8 +97,18 @@ class EagerTrainer:
 
         # ---- forward: fake = G(noise, c2); D on the [new_image ; fake] batch (eager_trainer.py:134-137)
         ctx_g: dict = {}
-        d_in = torch.empty((2 * B,) + tuple(img1.shape[1:]), dtype=torch.float32, device=self.device)
-        d_in[:B].copy_(new_image)
+        # D's input batch [new_image ; fake].  A caller that owns the step inputs hands the 2B-image buffer over as
+        # inp["disc_input"] with new_image ALREADY in its first half (`_train_step` lets the augmentation kernel write there,
+        # bench.py generates its synthetic new_image there): G writes `fake` into the second half and nothing is copied.
+        d_in = inp.get("disc_input")
+        if d_in is None:
+            d_in = torch.empty((2 * B,) + tuple(img1.shape[1:]), dtype=torch.float32, device=self.device)
+            d_in[:B].copy_(new_image)
+        elif not (tuple(d_in.shape) == (2 * B,) + tuple(img1.shape[1:]) and d_in.dtype == torch.float32 and d_in.is_contiguous()
+                  and d_in.device == new_image.device and d_in.data_ptr() == new_image.data_ptr()
+                  and tuple(new_image.shape) == tuple(img1.shape) and new_image.is_contiguous()):
+            raise ValueError("train_step_from_inputs: inp['disc_input'] must be a contiguous fp32 [2B, H, W, C] buffer whose first B "
+                             "images ARE inp['new_image'] (a view of it)")
         fake = G([noise, c2], ctx_g, out=d_in[B:])
         ctx_d: dict = {}
         run_adj = bool(a.train_adj and batch_no > 10)
@@ -128,8 +138,7 @@ class EagerTrainer:
         # ---- adjuster branch (eager_trainer.py:152-164)
         adj_image = None
         if run_adj:
-            adj_in_cond = (torch.cat([c2, c1], 0) + 1.0) * 0.5
-            adj_t_cond = torch.cat([c2, c1], 0)
+            adj_t_cond, adj_in_cond = ops.adj_conditions(c2, c1)   # concat([c2, c1], 0) and (that + 1) * 0.5, one launch
             ctx_a: dict = {}
             # encoder(fake) was computed by D above with the same weights: hand its 4 maps to the Adjuster
             tails = [m[B:] for m in ctx_d["enc_maps"]]  # fp32 maps (f32 path) / bf16 mirrors + the fp32 top map (bf16 path)
@@ -190,8 +199,11 @@ class EagerTrainer:
         if not hasattr(self, "_graphs"):
             self._graphs, self._graph_pool, self._graph_seen = {}, None, set()
             self._graph_in = {k: torch.empty_like(v) for k, v in inp.items()}
+            if "disc_input" in inp:   # new_image must stay the first half of the static 2B-image buffer
+                self._graph_in["new_image"] = self._graph_in["disc_input"][:inp["new_image"].shape[0]]
         for k, v in inp.items():
-            self._graph_in[k].copy_(v)
+            if k != "disc_input":     # (its first half arrives as new_image, its second half is written by the step)
+                self._graph_in[k].copy_(v)
         if kind not in self._graphs:
             if kind not in self._graph_seen:  # first step of this kind: eager (sizes workspaces, builds every lazy static)
                 self._graph_seen.add(kind)
@@ -222,13 +234,15 @@ class EagerTrainer:
             return None,
         if not real_cond_1.shape[0] == real_cond_2.shape[0] == self.args.batch_size:
             return False,
-        noise, new_image = self.draw_step_inputs(real_image_1)
+        # the augmented batch is written straight into the first half of D's [new_image ; fake] input
+        d_in = torch.empty((2 * real_image_1.shape[0],) + tuple(real_image_1.shape[1:]), dtype=torch.float32, device=self.device)
+        noise, new_image = self.draw_step_inputs(real_image_1, out=d_in[:real_image_1.shape[0]])
         inp = dict(real_image_1=real_image_1, real_cond_1=real_cond_1, real_image_2=real_image_2,
-                   real_cond_2=real_cond_2, noise=noise, new_image=new_image)
+                   real_cond_2=real_cond_2, noise=noise, new_image=new_image, disc_input=d_in)
         fake, adj, lg, ld, la = self.train_step_from_inputs(batch_no, inp)
         return True, fake, adj, lg, ld, la
 
-    def draw_step_inputs(self, real_image_1):
+    def draw_step_inputs(self, real_image_1, out=None):
         """eager_trainer.py:125-131 on the device: noise ~ N(0,1) and the augmented copy of the first real batch.  All
         draws are counter-based (Philox4x32-10 keyed by args.seed and the rank; one 2^40-block counter window per step),
         so a step's inputs can be regenerated from (seed, rank, step) alone."""
@@ -242,7 +256,7 @@ class EagerTrainer:
         # made ON THE DEVICE (lg_augment_drawn): random_brightness(0.02), random_contrast(0.75, 1.003), random_hue(0.03),
         # random_flip_left_right, + 0.1 * N(0, 0.2) from the window at 2^38 — no host synchronisation in the step
         new_image = ops.augment_drawn(real_image_1.contiguous(), 0.02, 0.75, 1.003, 0.03, 0.1 * 0.2, seed,
-                                      base + (1 << 39), base + (1 << 38))
+                                      base + (1 << 39), base + (1 << 38), out=out)
         return noise, new_image
 
     # ------------------------------------------------------------------ eager_trainer.py:180-229

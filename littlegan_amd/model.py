@@ -267,18 +267,17 @@ class Decoder(_ConvStack):
         a = self.args.leaky_alpha
         packs = self.packs()
         saved = []
-        if add[0] is not None:  # tiny (init_dim^2 x conv_filter[0]); later skips are fused into the norm-apply pass
-            if isinstance(add[0], tuple):  # (first rows, remaining rows) of the batch: two adds into one new tensor, no concatenated copy
-                b1 = add[0][0].shape[0]
-                xs = torch.empty_like(x)
-                torch.add(x[:b1], add[0][0], out=xs[:b1])
-                torch.add(x[b1:], add[0][1], out=xs[b1:])
-                x = xs
-            else:
-                x = x + add[0]
         m16 = self.dtype == DT_BF16
-        # level 1's input (dense + norm output, plus the first skip) is tiny: its bf16 mirror is a plain cast
-        x16 = x.to(torch.bfloat16) if m16 else None
+        # level 1's input: `x` is the dense + norm output with the first skip (add[0]) ALREADY added by the producer's apply
+        # launch (_DenseNorm.__call__(skip=...), model.py:44-46 `x += add[0]`), given as (fp32, bf16 mirror | None)
+        if isinstance(x, tuple):
+            x, x16 = x
+        else:
+            if add[0] is not None:
+                raise ValueError("Decoder: pass the level-1 input as the pair _DenseNorm.__call__(..., skip=add[0]) returns")
+            x16 = None
+        if m16 and x16 is None:
+            raise ValueError("Decoder: the bf16 path needs the bf16 mirror of its input (_DenseNorm.__call__(want16=True))")
         for i, (cb, cs) in enumerate(self.chans, 1):
             gm, bt = self._w[f"norm{i}.gamma"], self._w[f"norm{i}.beta"]
             z, st = ops.convT_s2_fwd_stats(x, packs[i - 1], self._w[f"conv{i}.bias"], cb, self.dtype, gm, bt, x16=x16,
@@ -350,11 +349,9 @@ class Decoder(_ConvStack):
             else:
                 # bf16 path: every data gradient of the decoder leaves its conv as bf16 — also level 1's, which the dense + norm
                 # backward reads as fp32: the persistent bf16-output kernels (conv_down3.hip) then cover that level too (its
-                # fp32-output route was the last user of the round-1 halo kernel here, 150-200 us per call against ~100), and the
-                # widening cast of an 8 x 8 x 384 map is ~6 us
+                # fp32-output route was the last user of the round-1 halo kernel here, 150-200 us per call against ~100); the dense
+                # layer's norm backward takes the bf16 gradient as it is (lg_instnorm_leaky_bwd: g_is_bf16)
                 g_h = ops.convT_s2_dgrad(dz, packs[i - 1], cs, self.dtype, dy16=dz16, out_bf16=self.dtype == DT_BF16)
-                if i == 1 and g_h.dtype == torch.bfloat16:
-                    g_h = g_h.float()
         return g_h if need_input_grad else None
 
 
@@ -420,14 +417,26 @@ class _DenseNorm(_Module):
         self._add("norm.gamma", (1,), "ones")
         self._add("norm.beta", (1,), "zeros")
 
-    def __call__(self, x, ctx: Optional[dict] = None):
+    def __call__(self, x, ctx: Optional[dict] = None, skip=None, want16: bool = False):
+        """Returns (w, w16): the [B, init_dim, init_dim, conv_filter[0]] map the decoder starts from, as fp32 and (want16) its
+        bf16 mirror.  skip (optional): the decoder's first skip tensor, added in the SAME apply launch (model.py:44-46 `x += add[0]`),
+        as a tensor or a pair (first rows, remaining rows) of the batch."""
         a = self.args.leaky_alpha
         u = ops.dense_fwd(x, self._w["dense.kernel"], self._w["dense.bias"])
         st = ops.instnorm_stats(u, self._w["norm.gamma"], self._w["norm.beta"], 1, a)
-        w = ops.instnorm_apply(u, st, None, 1, 0, a)
+        w16 = torch.empty(u.shape, dtype=torch.bfloat16, device=u.device) if want16 else None
+        if isinstance(skip, tuple):
+            b1 = skip[0].shape[0]
+            w = torch.empty_like(u)
+            for lo, hi, sk in ((0, b1, skip[0]), (b1, u.shape[0], skip[1])):
+                ops.instnorm_apply(u[lo:hi], st[lo:hi], sk.reshape(hi - lo, -1), 1, 0, a, out=w[lo:hi],
+                                   out16=w16[lo:hi] if want16 else None)
+        else:
+            w = ops.instnorm_apply(u, st, skip.reshape(u.shape) if skip is not None else None, 1, 0, a, out16=w16)
         if ctx is not None:
             ctx["dn"] = (x, u, st)
-        return w.view(-1, self.args.init_dim, self.args.init_dim, self.args.conv_filter[0])
+        shp = (-1, self.args.init_dim, self.args.init_dim, self.args.conv_filter[0])
+        return w.view(shp), (w16.view(shp) if want16 else None)
 
     def backward(self, ctx, g):
         x, u, st = ctx["dn"]
@@ -463,8 +472,8 @@ class Generator(_Module):
 
     def __call__(self, inputs, ctx: Optional[dict] = None, out=None):
         noise, cond = inputs
-        x0 = torch.cat([noise, cond], dim=-1).contiguous()
-        w4 = self._dn(x0, ctx)
+        x0 = ops.concat_cols(noise, cond)
+        w4 = self._dn(x0, ctx, want16=self.dtype == DT_BF16)
         xdec, xdec16 = self.decoder([w4, [None] * 4], ctx)
         img = self.conv(xdec, out=out, x16=xdec16)
         if ctx is not None:
@@ -600,13 +609,14 @@ class Adjuster(_Module):
             # `image` holds the leading samples only (or the whole batch: then its trailing rows are the ones already encoded)
             own = cond.shape[0] - enc_tails[0].shape[0]
             enc = self.encoder(image[:own], None, tails=enc_tails)
-        c4 = self._dn(cond.contiguous(), ctx)
+        # the decoder's first skip (the encoder's top map, model.py:131-135) is added by the dense-norm apply launch
+        c4 = self._dn(cond, ctx, skip=enc[3], want16=self.dtype == DT_BF16)
         # the Adjuster's tape differentiates dense + norm only (eager_trainer.py:51,62,163): nothing ever reads the decoder's
         # normalised last map again, so the final layer takes the raw map and normalises while it stages (bf16 path)
         side = self.args.init_dim * 16
         raw = self.conv.raw_supported(side, side)
         dctx = ctx if ctx is not None else ({} if raw else None)
-        x, x16 = self.decoder([c4, enc[::-1]], dctx, raw_last=raw)
+        x, x16 = self.decoder([c4, [None] + enc[::-1][1:]], dctx, raw_last=raw)
         if raw and x is None and x16 is None:
             img = self.conv.from_raw(dctx["dec"][3][1], dctx["dec"][3][2])
         else:

@@ -22,6 +22,7 @@ class Profile:
     Events are recorded on torch's current stream = the stream the kernels are launched on."""
     enabled = False
     records = []  # (tag, algorithmic flops, start event, end event)
+    after_conv = None  # bench.py's clock leg: called (no arguments) right behind every timed conv-class launch, on the launch stream
 
     @classmethod
     def start(cls):
@@ -43,6 +44,7 @@ class Profile:
 def _pb():
     if not Profile.enabled:
         return None
+    _lib.load().lg_clear_kernel()   # lg_last_kernel is sticky: a launch path that names no kernel must not inherit the previous call's
     e = torch.cuda.Event(enable_timing=True)
     e.record()
     return e
@@ -53,8 +55,10 @@ def _pe(e0, tag, flops):
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        kern = _lib.load().lg_last_kernel().decode()
+        kern = _lib.load().lg_last_kernel().decode() or tag   # unnamed launch path: filed under its class tag
         Profile.records.append((f"{tag}:{kern}", float(flops), e0, e1))
+        if Profile.after_conv is not None:
+            Profile.after_conv()
 
 
 def _stream():
@@ -595,6 +599,30 @@ def dense_wgrad(x, dy, dw, db, accumulate=False):
     _chk(dw, (K, N), "dw")
     check(_lib.load().lg_dense_wgrad(_p(x), _p(dy), _p(dw), _p(db), B, K, N, int(accumulate), _stream()),
           "lg_dense_wgrad")
+
+
+def concat_cols(a, c, out=None):
+    """[a | c] along the last axis (the Generator's dense input, model.py:97-98)."""
+    B, ka = a.shape
+    kc = c.shape[1]
+    _chk(a, name="a")
+    _chk(c, (B, kc), "c")
+    if out is None:
+        out = torch.empty(B, ka + kc, dtype=torch.float32, device=a.device)
+    _chk(out, (B, ka + kc), "out")
+    check(_lib.load().lg_concat_cols(_p(a), ka, _p(c), kc, _p(out), B, _stream()), "lg_concat_cols")
+    return out
+
+
+def adj_conditions(first, second):
+    """(t, u) = (concat([first, second], 0), (t + 1) * 0.5): the Adjuster's target / input conditions (eager_trainer.py:153-154)."""
+    B, c = first.shape
+    _chk(first, name="first")
+    _chk(second, (B, c), "second")
+    t = torch.empty(2 * B, c, dtype=torch.float32, device=first.device)
+    u = torch.empty_like(t)
+    check(_lib.load().lg_adj_conditions(_p(first), _p(second), _p(t), _p(u), B, c, _stream()), "lg_adj_conditions")
+    return t, u
 
 
 def dense_dgrad(dy, w, out=None):

@@ -646,6 +646,20 @@ def test_dense_dgrad(ops, B, K, N):
     assert rel(dx, dy @ w.T) < 3e-5
 
 
+@pytest.mark.parametrize("B,ka,kc", [(1, 3, 5), (7, 93, 40), (256, 93, 40), (512, 11, 7)])
+def test_step_input_forming_kernels(ops, B, ka, kc):
+    """lg_concat_cols = keras concatenate([noise, cond], -1) (model.py:97-98); lg_adj_conditions = tf.concat([c2, c1], 0) and
+    (that + 1) * 0.5 (eager_trainer.py:153-154): exact copies / one fp32 add and multiply, so the comparison is bit for bit."""
+    rng = np.random.default_rng(B * 100 + ka)
+    a, c, c1 = r32(rng, B, ka), r32(rng, B, kc), r32(rng, B, kc)
+    out = ops.concat_cols(dev(a), dev(c))
+    assert np.array_equal(out.cpu().numpy(), np.concatenate([a, c], -1))
+    t, u = ops.adj_conditions(dev(c), dev(c1))
+    t_ref = np.concatenate([c, c1], 0)
+    assert np.array_equal(t.cpu().numpy(), t_ref)
+    assert np.array_equal(u.cpu().numpy(), (t_ref + np.float32(1.0)) * np.float32(0.5))
+
+
 @pytest.mark.parametrize("case", [(4, 8, 16, 64, 128, False), (3, 16, 16, 64, 128, True), (2, 8, 16, 128, 64, True), (6, 8, 8, 64, 128, False)])
 def test_deferred_moments_finished_by_the_apply_launch(ops, case):
     """lg_instnorm_leaky_apply_z16_p (finalize + apply in one launch; with a bf16 skip over two row ranges as the Adjuster's

@@ -283,6 +283,59 @@ def test_graph_replay_is_bit_exact():
     assert len(tr_g._graphs) == 5   # (-1, False), (-1, True) and the three partition groups with the Adjuster on
 
 
+@pytest.mark.parametrize("mfma", ["f32", "bf16"])
+def test_handed_over_disc_input_is_bit_identical(mfma):
+    """inp["disc_input"] (the caller owns D's [new_image ; fake] batch and has new_image in its first half: what _train_step and
+    bench.py do) against the copying path, eager and through captured graphs: same images, losses, weights and Adam slots."""
+    cfg = O.Cfg(init_dim=2, conv_filter=(64, 32, 32, 64, 32), cond_dim=5, noise_dim=11, batch_size=3)
+    W = perturbed(cfg, 6)
+    tr_c, tr_h, tr_g = build(cfg, W, mfma), build(cfg, W, mfma), build(cfg, W, mfma)
+    B = cfg.batch_size
+    for b in (9, 11, 12, 13, 15, 16):
+        inp = dev_inputs(f32_round(O.make_inputs(cfg, B, seed=700 + b)))
+        d_in = torch.full((2 * B,) + tuple(inp["new_image"].shape[1:]), float("nan"), device="cuda")
+        d_in[:B].copy_(inp["new_image"])
+        handed = dict(inp, new_image=d_in[:B], disc_input=d_in)
+        fc, ac, lgc, ldc, lac = tr_c.train_step_from_inputs(b, inp)
+        fh, ah, lgh, ldh, lah = tr_h.train_step_from_inputs(b, handed)
+        fg, ag, lgg, ldg, lag = tr_g.graph_step(b, handed)
+        torch.cuda.synchronize()
+        assert fh.data_ptr() == d_in[B:].data_ptr()   # the Generator wrote straight into the handed-over buffer
+        for f2, a2, lg2, ld2 in ((fh, ah, lgh, ldh), (fg, ag, lgg, ldg)):
+            assert torch.equal(fc, f2) and torch.equal(lgc, lg2) and torch.equal(ldc, ld2), b
+            assert (ac is None) == (a2 is None) and (ac is None or torch.equal(ac, a2)), b
+        for t in (tr_h, tr_g):
+            assert torch.equal(tr_c.store.flat, t.store.flat) and torch.equal(tr_c.store.m, t.store.m) and torch.equal(tr_c.store.v, t.store.v), b
+    with pytest.raises(ValueError):   # a buffer whose first half is NOT new_image is refused
+        tr_h.train_step_from_inputs(17, dict(inp, disc_input=torch.empty_like(d_in)))
+
+
+def test_cu_budget_and_contention_rehearsal_do_not_change_results():
+    """Data-parallel plumbing on one GPU (littlegan_amd/dist.py): persistent grids sized to fewer CUs (lg_set_reserved_cus) and the
+    side-stream contention rehearsal at the three GradSync.launch points (lg_contention_probe) leave every bit of the step as it
+    is — items are dealt to fewer blocks, their partial records are per tile, not per block."""
+    cfg = O.Cfg(init_dim=2, conv_filter=(64, 32, 32, 64, 32), cond_dim=5, noise_dim=11, batch_size=3)
+    W = perturbed(cfg, 8)
+    ref, tst = build(cfg, W, "bf16"), build(cfg, W, "bf16")
+    try:
+        for b, reserve, k in ((11, 32, 0), (12, 0, 16), (13, 8, 8), (15, 100, 4)):
+            inp = dev_inputs(f32_round(O.make_inputs(cfg, cfg.batch_size, seed=800 + b)))
+            ref.sync.reserve_cus(0)
+            fr, ar, lgr, ldr, lar = ref.train_step_from_inputs(b, inp)
+            tst.sync.reserve_cus(reserve)
+            tst.sync.rehearse(k)
+            ft, at, lgt, ldt, lat = tst.train_step_from_inputs(b, inp)
+            torch.cuda.synchronize()
+            assert torch.equal(fr, ft) and torch.equal(ar, at) and torch.equal(lgr, lgt) and torch.equal(ldr, ldt) and torch.equal(lar, lat), b
+            assert torch.equal(ref.store.flat, tst.store.flat) and torch.equal(ref.store.m, tst.store.m), b
+    finally:
+        tst.sync.rehearse(0)
+        tst.sync.reserve_cus(0)
+    from littlegan_amd import _lib
+    with pytest.raises(_lib.LittleGanHipError):
+        tst.sync.reserve_cus(_lib.load().lg_device_cus())   # nothing left to run on
+
+
 def test_graph_replay_survives_workspace_growth():
     """A captured graph holds the raw addresses of ops.workspace() scratch buffers.  When a later, larger call outgrows one
     of them the old buffer must stay allocated (retired), not go back to the caching allocator where a new tensor could land
