@@ -353,11 +353,14 @@ def main():
         # HBM-side bytes per launch of that kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) cannot run inside this process;
         # they are collected on this same command and committed (scripts/collect_profiles.sh -> scripts/pmc_traffic.py)
         traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_pmc_traffic.json")
-        if a.workload == "c3" and dt_name == "bf16" and world == 1 and os.path.exists(tpath):
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")),
+                        key=lambda f: int(os.path.basename(f)[1:].split("_")[0]))
+        if a.workload == "c3" and dt_name == "bf16" and world == 1 and tfiles:
+            tpath = tfiles[-1]   # the newest round's counter passes
             rec = json.load(open(tpath)).get(tag)
             if rec:
-                traffic, traffic_src = rec["bytes_per_launch"], "profiles/r3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, offline; goes stale when the kernel changes)"
+                traffic, traffic_src = rec["bytes_per_launch"], f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, offline; goes stale when the kernel changes)"
         conv_sec = sum(v[2] for v in prof.values())
         conv_fl = sum(v[1] for v in prof.values())
         nsteps_prof = 5 if a.graph else a.steps

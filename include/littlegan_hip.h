@@ -200,6 +200,21 @@ int lg_conv2d_s2_dgrad_nf(const void* dy16, const void* pack, void* dx16, int B,
 int lg_convT_s2_dgrad_nf(const void* dy16, const void* pack, void* dx16, int B, int Hs, int Ws, int cb, int cs,
                          const void* z16, const float* stats, float alpha, void* part, size_t part_bytes, int* nparts,
                          void* stream);
+
+/* The same data gradient fed with the level's RAW pair (z16, g16) instead of dz16: the InstanceNorm + LeakyReLU backward of the
+ * level (instance.py:105-128 differentiated) is applied while the operand is staged, from the per-sample records `coef`
+ * (lg_instnorm_bwd_coef), so the norm-backward apply pass and the dz tensor do not exist.  For tapes that ask the level for no
+ * weight gradient (eager_trainer.py:158-163: the Adjuster differentiates its dense + norm only).  Always with the fused sums of the
+ * level below (zl16, stats_l, alpha_l -> part / nparts, as lg_convT_s2_dgrad_nf).  Bit-identical to lg_instnorm_leaky_bwd_z16_p +
+ * lg_convT_s2_dgrad_nf.  Hs x Ws = the small (output) map; z16, g16: [B][2Hs][2Ws][cb]; dx16: [B][Hs][Ws][cs]. */
+int lg_convT_s2_dgrad_bn_supported(int B, int Hs, int Ws, int cb, int cs);
+int lg_convT_s2_dgrad_bn(const void* z16, const void* g16, const float* coef, float alpha, const void* pack, void* dx16,
+                         int B, int Hs, int Ws, int cb, int cs, const void* zl16, const float* stats_l, float alpha_l,
+                         void* part, size_t part_bytes, int* nparts, void* stream);
+/* coef[B][8] = {mu_hi, mu_lo, a, beta, m1_hi, m2'_hi, m1_lo, m2'_lo} from the statistics records and the producer-fused sums
+ * {sum g', sum g' c} ([B][nparts][2] doubles): the norm backward without its apply pass (L = elements per sample) */
+int lg_instnorm_bwd_coef(const float* stats, const void* partials, int nparts, float* coef, int B, long long L, void* stream);
+
 int lg_convT_s1_tanh_bwd_nf(const float* x, const void* x16, const float* dpre, const void* pack, void* dx16, float* dw,
                             float* db, void* workspace, size_t ws_bytes, int B, int H, int W, int cb, int cs, int accumulate,
                             int dtype, const void* z16, const float* stats, float alpha, void* part, size_t part_bytes,

@@ -67,6 +67,9 @@ SIGNATURES = {
     "lg_instnorm_leaky_bwd_z16_p": (I, [P, P, P, I, P, P, P, P, P, I, P, I, P, Z, I, L, I, I, F, I, P]),
     "lg_conv2d_s2_dgrad_nf": (I, [P, P, P, I, I, I, I, I, P, P, F, P, Z, P, P]),
     "lg_convT_s2_dgrad_nf": (I, [P, P, P, I, I, I, I, I, P, P, F, P, Z, P, P]),
+    "lg_convT_s2_dgrad_bn_supported": (I, [I, I, I, I, I]),
+    "lg_convT_s2_dgrad_bn": (I, [P, P, P, F, P, P, I, I, I, I, I, P, P, F, P, Z, P, P]),
+    "lg_instnorm_bwd_coef": (I, [P, P, I, P, I, L, P]),
     "lg_convT_s1_tanh_bwd_nf": (I, [P, P, P, P, P, P, P, P, Z, I, I, I, I, I, I, I, P, P, F, P, Z, P, P]),
     "lg_dense_fwd": (I, [P, P, P, P, I, I, I, P]),
     "lg_dense_wgrad": (I, [P, P, P, P, I, I, I, I, P]),

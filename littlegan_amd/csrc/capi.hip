@@ -219,6 +219,25 @@ extern "C" int lg_convT_s2_dgrad_nf(const void* dy16, const void* pack, void* dx
   return lg_convT_s2_dgrad_m16(nullptr, dy16, pack, nullptr, dx16, B, Hs, Ws, cb, cs, LG_DT_BF16, stream);
 }
 
+extern "C" int lg_conv_down3_bn_supported(int B, int Hm, int Wm, int Cs, int N);
+extern "C" int lg_conv_down3_bn_try(const void* z16, const void* g16, const float* bcoef, float alpha, const void* wpack, void* out16,
+                                    int B, int Hm, int Wm, int Cs, int N, int* nparts_out, const LgNormFuse* nf, size_t nf_bytes,
+                                    void* stream);
+extern "C" int lg_convT_s2_dgrad_bn_supported(int B, int Hs, int Ws, int cb, int cs) {
+  return cb != 3 ? lg_conv_down3_bn_supported(B, Hs, Ws, cb, cs) : 0;
+}
+extern "C" int lg_convT_s2_dgrad_bn(const void* z16, const void* g16, const float* coef, float alpha, const void* pack, void* dx16,
+                                    int B, int Hs, int Ws, int cb, int cs, const void* zl16, const float* stats_l, float alpha_l,
+                                    void* part, size_t part_bytes, int* nparts, void* stream) {
+  LG_CHECK_ARG(z16 && g16 && coef && pack && dx16 && zl16 && stats_l && part && nparts, "lg_convT_s2_dgrad_bn: null pointer");
+  *nparts = 0;
+  LgNormFuse nf{(const __bf16*)zl16, stats_l, (double*)part, alpha_l, 0};
+  const int rc = lg_conv_down3_bn_try(z16, g16, coef, alpha, pack, dx16, B, Hs, Ws, cb, cs, nparts, &nf, part_bytes, stream);
+  if (rc == LG_ERR_UNSUPPORTED) lg_set_error("lg_convT_s2_dgrad_bn: shape B=%d %dx%d cb=%d cs=%d has no backward-normalising kernel "
+                                             "(see lg_convT_s2_dgrad_bn_supported)", B, Hs, Ws, cb, cs);
+  return rc;
+}
+
 extern "C" int lg_conv2d_s2_wgrad_m16(const float* x, const void* x16, const float* dy, const void* dy16, float* dw,
                                       void* workspace, size_t ws_bytes, int B, int Hs, int Ws, int cb, int cs,
                                       int accumulate, int dtype, void* stream) {

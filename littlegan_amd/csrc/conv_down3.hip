@@ -73,8 +73,10 @@ struct D3Params {
   int B, Hs, Ws, Cs, Hm, Wm, N, N32, KB;
   int tpi_x, tpi, ntn, nitems, nparts;
   LgNormFuse nf;       // FUSE instantiation: norm-backward sums of the produced gradient (lg_common.h)
-  const float* nstats; // NORM instantiation: src is the RAW output z of the layer below, these are its statistics records [B][8]
+  const float* nstats; // NORM = 1: src is the RAW output z of the layer below, these are its statistics records [B][8]
   float nalpha;        //   ... and the operand is bf16(leaky(InstanceNorm(z))), formed while the halo is staged
+  const __bf16* gsrc;  // NORM = 2 (BWDNORM): src is the raw output z of THIS level, gsrc the gradient g w.r.t. its normalised + activated
+  const float* bcoef;  //   map, bcoef the per-sample records of lg_instnorm_bwd_coef: the operand dz is formed while the halo is staged
   int stagger;         // start delay of the odd-slot block in ~1024-cycle units
   unsigned long long* stamps;  // diagnostic build only (LG_D3_STAMPS): [block][64] s_memtime stamps of wave 0
   int stamp_lite;              // only the block's first / last stamp (the per-phase stamps cost ~11 % and change the clock)
@@ -103,10 +105,17 @@ constexpr int toff_bytes(int t) {  // tap t = ky*5+kx: LDS byte offset of its so
 // conv2 (64 -> 128 channels, 64 x 64 map) 101 + 266 -> 272 us; conv3 (128 -> 256, 32 x 32) 46 + 197 -> 227 us.  The sample-PAIR
 // tiling of the 8 x 8 level was built too and LOSES (conv4: 27 + 189 -> 228 us: 16 slices per item, each re-normalising a halo the
 // three column tiles share) — it has no normalising form.
-template <bool STATS, bool FUSE = false, bool PAIR = false, int NW = 128, bool NORM = false>
+// NORM = 2 (BWDNORM, round 4): the data gradient of a transposed conv whose incoming gradient has not been taken through the
+// InstanceNorm + LeakyReLU backward yet.  The source is the pair (z, g) of the level; dz = a (g' - m1 - c m2') — bwd_apply16_kernel's
+// arithmetic and rounding, lg_bwdnorm8 — is formed per 16-B halo piece between the two buffer loads and the LDS store, so the
+// norm-backward apply pass and its dz tensor disappear (6 B per element of HBM traffic less; the piece loads double).  For tapes that
+// ask the level for no weight gradient: the Adjuster's decoder chain at 2B (eager_trainer.py:158-163), partition steps of the
+// Generator.  Bit-identical to bwd_apply16 + conv (tests/test_launch_shapes_gpu.py).  Weight ring of 5 at NW = 128 (register budget).
+template <bool STATS, bool FUSE = false, bool PAIR = false, int NW = 128, int NORM = 0>
 __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   static_assert(!(STATS && FUSE), "forward moments and backward sums are never needed together");
-  static_assert(!NORM || (STATS && NW == 128 && !PAIR), "the normalising form exists for the forward passes with fused moments, 8 x 16 tiles");
+  static_assert(NORM != 1 || (STATS && NW == 128 && !PAIR), "the normalising form exists for the forward passes with fused moments, 8 x 16 tiles");
+  static_assert(NORM != 2 || (!STATS && !PAIR), "the backward-normalising form exists for the data gradients on 8 x 16 tiles");
   static_assert(NW == 128 || (NW == 64 && !PAIR), "tile widths");
   constexpr int NWV = NW / 32, NI = NW / 32;          // waves along the channels; 32-pixel groups per wave (4 | 2)
   constexpr int PPR = NW / 8, NQ = 128 * PPR / 256;   // 16-B pieces per output pixel row; pieces per thread in the row sweep
@@ -177,10 +186,15 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   // the slice boundary — where this wave issues no MFMA — is what a lone wave per SIMD pays in full (r3 census: 60 % of the pipe).
   unsigned hoff[PPT];
   float nmu0 = 0.f, nml0 = 0.f, nna0 = 0.f, nnb0 = 0.f;   // NORM: the item's sample
+  LgBwdCoef bco{};                                         // BWDNORM: the item's sample
   auto set_item = [&](const Item& it) __attribute__((always_inline)) {
-    if constexpr (NORM) {
+    if constexpr (NORM == 1) {
       const float* sp = p.nstats + (long long)it.n * 8;   // uniform: scalar loads
       nmu0 = sp[0]; nna0 = sp[2]; nnb0 = sp[3]; nml0 = sp[4];
+    }
+    if constexpr (NORM == 2) {
+      const float* sp = p.bcoef + (long long)it.n * 8;    // uniform: one 32-byte scalar load
+      bco.mu = sp[0]; bco.mul = sp[1]; bco.a = sp[2]; bco.b = sp[3]; bco.m1 = sp[4]; bco.m2 = sp[5]; bco.m1l = sp[6]; bco.m2l = sp[7];
     }
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
@@ -196,12 +210,27 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
 #pragma unroll
     for (int u = 0; u < PPT; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hoff[u] + (unsigned)(c0 * 2), 0, 0));
   };
+  auto issue_g = [&](const Item& it, int c0, u32x4 (&v)[NORM == 2 ? PPT : 1]) __attribute__((always_inline)) {   // BWDNORM: the same pieces of g
+    if constexpr (NORM == 2) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<__bf16*>(p.gsrc + (long long)it.n * sample_elems), 0, sample_elems * 2, 0x00027000);
+#pragma unroll
+      for (int u = 0; u < PPT; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hoff[u] + (unsigned)(c0 * 2), 0, 0));
+    }
+  };
+  u32x4 gv[NORM == 2 ? PPT : 1];
   auto commit = [&](char* buf, const u32x4 (&v)[PPT]) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < PPT; ++u)
       if (pl[u] >= 0) {
         u32x4 w = v[u];
-        if constexpr (NORM) {   // (hoff is the offset this very piece was requested with: commit follows the issue of the same slice)
+        if constexpr (NORM == 2) {   // out-of-range pieces: z = g = 0 came back, but dz(0, 0) != 0 — the padding of dz is zero
+          const u32x4 dn = lg_bwdnorm8(w, gv[u], bco, p.nalpha);
+          const bool inside = hoff[u] != OOB;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) w[k] = inside ? dn[k] : 0u;
+        }
+        if constexpr (NORM == 1) {   // (hoff is the offset this very piece was requested with: commit follows the issue of the same slice)
           const u32x4 hn = lg_norm8(w, nmu0, nml0, nna0, nnb0, p.nalpha);
           const bool inside = hoff[u] != OOB;
 #pragma unroll
@@ -240,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   // Weight-fragment ring: RING fragments (= taps) ahead of the MFMAs.  25 taps per slice and RING = 10 -> the ring
   // position of tap 0 alternates between 0 and 5 from one slice to the next: the slice body exists in two copies
   // (OFF = 0 / 5) so that every ring access is a compile-time register.
-  constexpr int RING = LG_D3_RING;
+  constexpr int RING = (NORM == 2 && NW == 128) ? 5 : LG_D3_RING;   // (r2 A/B: a 5-tap ring is within +-3 % of the 10-tap one, 20 VGPRs less)
   constexpr int AD = LG_D3_ADEPTH;
   u32x4 bf[RING];
   u32x4 hv[PPT];
@@ -249,6 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   Item cur = decode(0);
   set_item(cur);
   issue(cur, 0, hv);
+  issue_g(cur, 0, gv);
 #pragma unroll
   for (int t = 0; t < RING; ++t) bf[t] = wfrag(wbase(cur.tn, 0), t);
   commit(smem, hv);
@@ -298,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
     int c2 = c + 1;
     if (last_c) { c2 = 0; if (more) { nxt = decode(k + 1); set_item(nxt); } }
     if (!more) c2 = c;  // final step: re-request the current slice (valid addresses, results unused) -> no branches below
-    if constexpr (!(DBG & 4)) issue(nxt, c2 * KC, hv);
+    if constexpr (!(DBG & 4)) { issue(nxt, c2 * KC, hv); issue_g(nxt, c2 * KC, gv); }
     const char* hbuf = smem + (s & 1) * HB;
     const char* wcur = wbase(cur.tn, c);
     const char* wnxt = wbase(nxt.tn, c2);
@@ -511,7 +541,7 @@ extern "C" int lg_conv_down3_try(const void* src16, const void* wpack, const flo
 // nf (optional; data-gradient use): also the norm-backward sums of the produced gradient ([B][*nparts_out][2] doubles)
 static int down3_launch(const void* src16, const void* wpack, const float* bias, void* out16, int B, int Hm, int Wm, int Cs, int N,
                         void* spart, size_t spart_bytes, int* nparts_out, const LgNormFuse* nf, size_t nf_bytes,
-                        const float* nstats, float nalpha, void* stream);
+                        const float* nstats, float nalpha, void* stream, const void* g16 = nullptr, const float* bcoef = nullptr);
 extern "C" int lg_conv_down3_supported(int B, int Hm, int Wm, int Cs, int N);
 extern "C" int lg_conv_down3_nf_try(const void* src16, const void* wpack, const float* bias, void* out16, int B, int Hm, int Wm,
                                     int Cs, int N, void* spart, size_t spart_bytes, int* nparts_out, const LgNormFuse* nf,
@@ -529,9 +559,25 @@ extern "C" int lg_conv_down3_zn_try(const void* z16, const float* zstats, float 
 extern "C" int lg_conv_down3_zn_supported(int B, int Hm, int Wm, int Cs, int N) {
   return (!lg_env_flag("LG_NO_D3_NORM") && N % 128 == 0 && Hm % TH == 0 && Wm % TW == 0 && lg_conv_down3_supported(B, Hm, Wm, Cs, N)) ? 1 : 0;
 }
+// BWDNORM form (NORM = 2): the data gradient of a transposed conv fed with (z16, g16, coef) of its level instead of dz16 — the
+// sums of the NEXT level's norm backward are always fused (nf), 8 x 16 tiles only; LG_ERR_UNSUPPORTED otherwise.
+extern "C" int lg_conv_down3_bn_supported(int B, int Hm, int Wm, int Cs, int N) {
+  const bool pair = Hm == 8 && Wm == 8 && B % 2 == 0;
+  // N = 128 x k with k > 1: every column tile would redo the dz arithmetic of the halo it shares — measured for the forward
+  // normalising form (conv3: + 30 us of 197), not built for the backward one
+  return (!lg_env_flag("LG_NO_D3_BWDNORM") && !pair && Hm % TH == 0 && Wm % TW == 0 && (N == 64 || N == 128) &&
+          lg_conv_down3_supported(B, Hm, Wm, Cs, N)) ? 1 : 0;
+}
+extern "C" int lg_conv_down3_bn_try(const void* z16, const void* g16, const float* bcoef, float alpha, const void* wpack, void* out16,
+                                    int B, int Hm, int Wm, int Cs, int N, int* nparts_out, const LgNormFuse* nf, size_t nf_bytes,
+                                    void* stream) {
+  if (nparts_out) *nparts_out = 0;
+  if (!g16 || !bcoef || !nf || !nparts_out || !lg_conv_down3_bn_supported(B, Hm, Wm, Cs, N)) return LG_ERR_UNSUPPORTED;
+  return down3_launch(z16, wpack, nullptr, out16, B, Hm, Wm, Cs, N, nullptr, 0, nparts_out, nf, nf_bytes, nullptr, alpha, stream, g16, bcoef);
+}
 static int down3_launch(const void* src16, const void* wpack, const float* bias, void* out16, int B, int Hm, int Wm, int Cs, int N,
                         void* spart, size_t spart_bytes, int* nparts_out, const LgNormFuse* nf, size_t nf_bytes,
-                        const float* nstats, float nalpha, void* stream) {
+                        const float* nstats, float nalpha, void* stream, const void* g16, const float* bcoef) {
   if (nparts_out) *nparts_out = 0;
   static int off = -1;
   if (off < 0) off = lg_env_flag("LG_NO_DOWN3") ? 1 : 0;  // A/B switch
@@ -558,7 +604,9 @@ static int down3_launch(const void* src16, const void* wpack, const float* bias,
   p.spart = stats ? (double*)spart : nullptr;
   if (fuse) p.nf = *nf;
   if (nstats && (!stats || n64 || pair)) return LG_ERR_UNSUPPORTED;
+  if (g16 && (!fuse || pair || nstats || p.ntn != 1)) return LG_ERR_UNSUPPORTED;
   p.nstats = nstats; p.nalpha = nalpha;
+  p.gsrc = (const __bf16*)g16; p.bcoef = bcoef;
   static int bpc = 0;   // resident blocks per CU
   if (!bpc) {
     bpc = 2;
@@ -572,14 +620,19 @@ static int down3_launch(const void* src16, const void* wpack, const float* bias,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<true, false, false, 64>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, false, false, 64>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, true, false, 64>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<true, false, false, 128, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<true, false, false, 128, 1>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, true, false, 128, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, true, false, 64, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
   }
   const int nblk = bpc * lg_grid_cus();   // every block resident from the start, also beside communication kernels (runtime.hip)
   const int grid = p.nitems < nblk ? p.nitems : nblk;
   hipStream_t st = (hipStream_t)stream;
   constexpr int LDS0 = D3L<false>::LDS_BYTES, LDS1 = D3L<true>::LDS_BYTES;
   if (nstats) {
-    hipLaunchKernelGGL((conv_down3_kernel<true, false, false, 128, true>), dim3(grid), dim3(256), LDS0, st, p);
+    hipLaunchKernelGGL((conv_down3_kernel<true, false, false, 128, 1>), dim3(grid), dim3(256), LDS0, st, p);
+  } else if (g16) {
+    if (n64) hipLaunchKernelGGL((conv_down3_kernel<false, true, false, 64, 2>), dim3(grid), dim3(256), LDS0, st, p);
+    else hipLaunchKernelGGL((conv_down3_kernel<false, true, false, 128, 2>), dim3(grid), dim3(256), LDS0, st, p);
   } else if (pair) {
     if (fuse) hipLaunchKernelGGL((conv_down3_kernel<false, true, true>), dim3(grid), dim3(256), LDS1, st, p);
     else if (stats) hipLaunchKernelGGL((conv_down3_kernel<true, false, true>), dim3(grid), dim3(256), LDS1, st, p);
@@ -592,7 +645,7 @@ static int down3_launch(const void* src16, const void* wpack, const float* bias,
   else if (stats) hipLaunchKernelGGL(conv_down3_kernel<true>, dim3(grid), dim3(256), LDS0, st, p);
   else hipLaunchKernelGGL(conv_down3_kernel<false>, dim3(grid), dim3(256), LDS0, st, p);
   LG_CHECK_LAUNCH("lg_conv_down3");
-  lg_note_kernel(nstats ? "conv_down3_kernel<NW=128,NORM>" : pair ? "conv_down3_kernel<PAIR>" : n64 ? "conv_down3_kernel<NW=64>" : "conv_down3_kernel<NW=128>");
+  lg_note_kernel(g16 ? (n64 ? "conv_down3_kernel<NW=64,BWDNORM>" : "conv_down3_kernel<NW=128,BWDNORM>") : nstats ? "conv_down3_kernel<NW=128,NORM>" : pair ? "conv_down3_kernel<PAIR>" : n64 ? "conv_down3_kernel<NW=64>" : "conv_down3_kernel<NW=128>");
   if (stats || fuse) *nparts_out = p.nparts;
   return LG_OK;
 }

@@ -147,6 +147,26 @@ __device__ __forceinline__ u32x4 lg_norm8(const u32x4 z8, float mu, float mul, f
   return o;
 }
 
+// 8 bf16 z, 8 bf16 g -> 8 bf16 dz of the InstanceNorm + LeakyReLU backward, exactly bwd_apply16_kernel (norm.hip) in its
+// post-LeakyReLU form: c = (z - mu) - mul; g' = (a c + b > 0) ? g : alpha g; dz = a ((((g' - m1) - m1l) - c m2) - c m2l); RNE.
+// co = the per-sample record {mu, mul, a, b, m1, m2, m1l, m2l} of lg_instnorm_bwd_coef
+struct LgBwdCoef { float mu, mul, a, b, m1, m2, m1l, m2l; };
+__device__ __forceinline__ u32x4 lg_bwdnorm8(const u32x4 z8, const u32x4 g8, const LgBwdCoef& co, float alpha) {
+  u32x4 o;
+  typedef __bf16 lg_bf16x2_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float z0 = __builtin_bit_cast(float, z8[k] << 16), z1 = __builtin_bit_cast(float, z8[k] & 0xffff0000u);
+    const float g0 = __builtin_bit_cast(float, g8[k] << 16), g1 = __builtin_bit_cast(float, g8[k] & 0xffff0000u);
+    const float c0 = (z0 - co.mu) - co.mul, c1 = (z1 - co.mu) - co.mul;
+    const float p0 = (co.a * c0 + co.b > 0.f) ? g0 : alpha * g0, p1 = (co.a * c1 + co.b > 0.f) ? g1 : alpha * g1;
+    const float d0 = co.a * ((((p0 - co.m1) - co.m1l) - c0 * co.m2) - c0 * co.m2l);
+    const float d1 = co.a * ((((p1 - co.m1) - co.m1l) - c1 * co.m2) - c1 * co.m2l);
+    o[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{d0, d1}, lg_bf16x2_));
+  }
+  return o;
+}
+
 // 8 consecutive channels of one pixel: g8 / z8 = 16 B of bf16 each
 __device__ __forceinline__ void lg_nf_accum(const u32x4 g8, const u32x4 z8, float mu, float mul, float a, float b, float alpha,
                                             float& s1, float& s2) {

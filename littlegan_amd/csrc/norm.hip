@@ -219,6 +219,26 @@ __global__ __launch_bounds__(64) void bwd_final_kernel(const double* __restrict_
   }
 }
 
+// coef[n][8] = {mu_hi, mu_lo, a, beta, m1_hi, m2'_hi, m1_lo, m2'_lo}: everything a consumer needs to form the norm backward's dz
+// of sample n from (z, g) on the fly (lg_bwdnorm8, lg_common.h) — the sums are merged exactly as bwd_final_kernel merges them
+__global__ __launch_bounds__(64) void bwd_coef_kernel(const double* __restrict__ partial, const float* __restrict__ stats,
+                                                      float* __restrict__ coef, long long L, int nchunk) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const double* p = partial + (long long)n * nchunk * 2;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = lane; i < nchunk; i += 64) { s1 += p[i * 2]; s2 += p[i * 2 + 1]; }
+  s1 = lg_wave_sum_d(s1); s2 = lg_wave_sum_d(s2);
+  if (lane == 0) {
+    const float* sp = stats + (long long)n * LG_NSTAT;
+    const double sigma = (double)sp[1], s = sigma + (double)LG_IN_EPS;
+    const double m1 = s1 / (double)L, m2 = s2 / (double)L / (s * sigma);
+    const float m1h = (float)m1, m2h = (float)m2;
+    float* o = coef + (long long)n * 8;
+    o[0] = sp[0]; o[1] = sp[4]; o[2] = sp[2]; o[3] = sp[3];
+    o[4] = m1h; o[5] = m2h; o[6] = (float)(m1 - (double)m1h); o[7] = (float)(m2 - (double)m2h);
+  }
+}
+
 __global__ __launch_bounds__(256) void bwd_affine_grad_kernel(const double* __restrict__ gsum, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int B, int accumulate) {
   __shared__ double sg[256], sb[256];
@@ -872,5 +892,17 @@ extern "C" int lg_instnorm_leaky_bwd_z16_p(const void* z16, const float* stats, 
   hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)colpart, db, (int)nb, C,
                      accumulate);
   LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd_z16(bias)");
+  return LG_OK;
+}
+
+// The norm backward WITHOUT its apply pass: coef[B][8] (see bwd_coef_kernel) from the statistics records and the sums
+// {sum g', sum g' c} the producer of g left as [B][nparts][2] doubles (lg_*_dgrad_nf).  The consumer of dz — the next data-gradient
+// conv (lg_convT_s2_dgrad_bn) — forms dz = a (g' - m1 - c m2') while it stages its operand: dz is never written.  For tapes that
+// ask the level for no weight gradient (dz then has ONE reader).  instance.py:105-128 differentiated; eager_trainer.py:158-163.
+extern "C" int lg_instnorm_bwd_coef(const float* stats, const void* partials, int nparts, float* coef, int B, long long L,
+                                    void* stream) {
+  LG_CHECK_ARG(stats && partials && coef && nparts > 0 && B > 0 && B <= 65535 && L > 0, "lg_instnorm_bwd_coef: bad arguments");
+  hipLaunchKernelGGL(bwd_coef_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const double*)partials, stats, coef, L, nparts);
+  LG_CHECK_LAUNCH("lg_instnorm_bwd_coef");
   return LG_OK;
 }

@@ -32,10 +32,12 @@ __device__ __forceinline__ void fo_decode(long long i, int npad, int K, int& t, 
 
 template <typename T>
 __global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ down, T* __restrict__ up, int Cb, int Cs,
-                            int npad_s, int npad_b, long long n_down, long long n_up) {
+                            int npad_s, int npad_b, long long n_down, long long n_up, float* __restrict__ raw, long long n_raw) {
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_down + n_up; i += stride) {
-    if (i < n_down) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_down + n_up + n_raw; i += stride) {
+    if (i >= n_down + n_up) {  // 3-channel layers: the verbatim fp32 copy (same launch: no runtime copy kernel in the step)
+      raw[i - n_down - n_up] = w[i - n_down - n_up];
+    } else if (i < n_down) {
       float v = 0.f;
       if (Cb == 3) {  // [5][npad_s][16]
         const int j = (int)(i % 16);
@@ -89,19 +91,16 @@ extern "C" int lg_conv_pack(const float* w, void* pack, int cb, int cs, int dtyp
   LG_CHECK_ARG(dtype == LG_DT_F32 || dtype == LG_DT_BF16, "lg_conv_pack: bad dtype %d", dtype);
   const long long nd = down_elems(cb, cs), nu = up_elems(cb, cs);
   char* up = (char*)pack + lg_conv_pack_up_offset(cb, cs, dtype);
-  const int blocks = (int)((nd + nu + 255) / 256 < 4096 ? (nd + nu + 255) / 256 : 4096);
+  const long long nr = cb == 3 ? 75ll * cs : 0;
+  float* raw = cb == 3 ? (float*)((char*)pack + lg_conv_pack_raw_offset(cb, cs, dtype)) : nullptr;
+  const int blocks = (int)((nd + nu + nr + 255) / 256 < 4096 ? (nd + nu + nr + 255) / 256 : 4096);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == LG_DT_F32)
     hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, st, w, (float*)pack, (float*)up, cb, cs,
-                       lg_npad(cs), lg_npad(cb), nd, nu);
+                       lg_npad(cs), lg_npad(cb), nd, nu, raw, nr);
   else
     hipLaunchKernelGGL(pack_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, w, (__bf16*)pack, (__bf16*)up, cb, cs,
-                       lg_npad(cs), lg_npad(cb), nd, nu);
+                       lg_npad(cs), lg_npad(cb), nd, nu, raw, nr);
   LG_CHECK_LAUNCH("lg_conv_pack");
-  if (cb == 3) {
-    hipError_t e = hipMemcpyAsync((char*)pack + lg_conv_pack_raw_offset(cb, cs, dtype), w, (size_t)75 * cs * 4,
-                                  hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) { lg_set_error("lg_conv_pack: raw copy failed: %s", hipGetErrorString(e)); return LG_ERR_LAUNCH; }
-  }
   return LG_OK;
 }

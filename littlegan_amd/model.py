@@ -25,6 +25,7 @@ from ._lib import DT_BF16, DT_F32
 
 import os as _os
 _ZN = not _os.environ.get("LG_NO_ZN")   # A/B switch: apply passes left to the consuming conv where no one else reads the map
+_BN = not _os.environ.get("LG_NO_BWDNORM")   # A/B switch: norm-backward apply left to the consuming data-gradient conv (no-weight-gradient levels)
 _DEFER = not _os.environ.get("LG_NO_DEFER")   # A/B switch: moments finished by the apply launch (default) or by their own kernel
 
 
@@ -332,6 +333,18 @@ class Decoder(_ConvStack):
             x, z, st, x16 = ctx["dec"][i - 1]
             dgm = self._g[f"norm{i}.gamma"] if need_wgrad else None
             dbt = self._g[f"norm{i}.beta"] if need_wgrad else None
+            want_dx = i > lowest or (i == 1 and need_input_grad)
+            # A level that is asked for NO weight gradient (the Adjuster's tapes, eager_trainer.py:158-163; partition steps) has one
+            # reader of its dz: the data-gradient conv below.  Where that kernel can take the norm backward through its operand
+            # staging (ops.convT_s2_dgrad_bn: dz = a (g' - m1 - c m2') formed from (z, g) per halo piece), the apply pass and the
+            # dz tensor are left out; only the per-sample coefficients are finished from the producer-fused sums.
+            if (_BN and not need_wgrad and want_dx and i > 1 and i - 1 >= lowest and nfp is not None and self.dtype == DT_BF16
+                    and z.dtype == torch.bfloat16 and g_h.dtype == torch.bfloat16
+                    and ops.convT_s2_dgrad_bn_supported(z.shape[0], z.shape[1] // 2, z.shape[2] // 2, cb, cs, self.dtype)):
+                coef = ops.instnorm_bwd_coef(z, st, nfp)
+                zl, stl = ctx["dec"][i - 2][1], ctx["dec"][i - 2][2]
+                g_h, nfp = ops.convT_s2_dgrad_bn(z, g_h, coef, a, packs[i - 1], cs, fuse=(zl, stl, a))
+                continue
             dz16 = torch.empty(z.shape, dtype=torch.bfloat16, device=z.device) if self.dtype == DT_BF16 else None
             drop32 = (dz16 is not None and (not need_wgrad or x16 is not None) and
                       ops.conv_halo_supported(0, self.dtype, z.shape[0], z.shape[1] // 2, z.shape[2] // 2, cb, cs))
@@ -340,7 +353,6 @@ class Decoder(_ConvStack):
             nfp = None
             if need_wgrad:
                 ops.convT_s2_wgrad(x, dz, self._g[f"conv{i}.kernel"], False, self.dtype, x16=x16, dy16=dz16)
-            want_dx = i > lowest or (i == 1 and need_input_grad)
             if not want_dx:
                 g_h = None
             elif dz16 is not None and drop32 and i > 1 and i - 1 >= lowest:

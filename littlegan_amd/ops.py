@@ -284,6 +284,47 @@ def convT_s2_dgrad(dy, pack, cs, dtype, out=None, dy16=None, out_bf16=False, fus
     return out
 
 
+def convT_s2_dgrad_bn_supported(B, Hs, Ws, cb, cs, dtype):
+    return dtype == DT_BF16 and bool(_lib.load().lg_convT_s2_dgrad_bn_supported(B, Hs, Ws, cb, cs))
+
+
+def instnorm_bwd_coef(z16, stats, partials):
+    """The norm backward WITHOUT its apply pass: per-sample records [B, 8] from the statistics and the producer-fused sums
+    (NormPartials).  The consumer (convT_s2_dgrad_bn) forms dz while it stages its operand."""
+    B = z16.shape[0]
+    _chk(stats, (B, NSTAT), "stats")
+    if tuple(z16.shape) != partials.shape:
+        raise ValueError(f"instnorm_bwd_coef: partial sums were produced for shape {partials.shape}, got {tuple(z16.shape)}")
+    coef = torch.empty(B, 8, dtype=torch.float32, device=z16.device)
+    check(_lib.load().lg_instnorm_bwd_coef(_p(stats), _p(partials.buf), int(partials.nparts), _p(coef), B, z16.numel() // B, _stream()),
+          "lg_instnorm_bwd_coef")
+    return coef
+
+
+def convT_s2_dgrad_bn(z16, g16, coef, alpha, pack, cs, fuse):
+    """Data gradient of Conv2DTranspose(cb, 5, 2, same) from the level's raw pair (z16, g16) [B, 2Hs, 2Ws, cb] + coef
+    (instnorm_bwd_coef): dz is formed on the fly.  fuse = (z16, stats, alpha) of the level below -> (dx16 [B, Hs, Ws, cs], NormPartials)."""
+    import ctypes
+    B, H, W, cb = z16.shape
+    _chk16(z16, z16, "z16")
+    _chk16(g16, z16, "g16")
+    if tuple(g16.shape) != tuple(z16.shape):
+        raise ValueError("convT_s2_dgrad_bn: z16 and g16 must have the same shape")
+    _chk(coef, (B, 8), "coef")
+    if not convT_s2_dgrad_bn_supported(B, H // 2, W // 2, cb, cs, DT_BF16):
+        raise ValueError(f"convT_s2_dgrad_bn: unsupported shape B={B} {H // 2}x{W // 2} cb={cb} cs={cs}")
+    out = torch.empty(B, H // 2, W // 2, cs, dtype=torch.bfloat16, device=z16.device)
+    zl, stl, alpha_l, ws, npo = _nf_args(fuse, B, False, H // 2, W // 2, cs, z16.device)
+    e0 = _pb()
+    check(_lib.load().lg_convT_s2_dgrad_bn(_p(z16), _p(g16), _p(coef), float(alpha), _p(pack), _p(out), B, H // 2, W // 2, cb, cs,
+                                          _p(zl), _p(stl), alpha_l, _p(ws), ws.numel(), ctypes.addressof(npo), _stream()),
+          "lg_convT_s2_dgrad_bn")
+    _pe(e0, "conv_igemm_down", 50.0 * B * (H // 2) * (W // 2) * cb * cs)
+    if npo.value <= 0:
+        raise _lib.LittleGanHipError("lg_convT_s2_dgrad_bn returned no partial sums")
+    return out, NormPartials(ws, npo.value, alpha_l, out.shape)
+
+
 def convT_s2_wgrad(x, dy, dw, accumulate, dtype, x16=None, dy16=None):
     """dw[5,5,cb,cs] (+)= wgrad(x [B,Hs,Ws,cs], dy [B,2Hs,2Ws,cb]); x16/dy16: optional bf16 mirrors"""
     return _wgrad("lg_convT_s2_wgrad_m16", dy, x, dw, accumulate, dtype, swap=True, big16=dy16, small16=x16)

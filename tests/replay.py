@@ -23,7 +23,7 @@ EPS = 1e-3  # InstanceNormalization epsilon (instance.py:47-58)
 
 RECORDED = ["conv_pack", "conv2d_s2_fwd_stats", "conv2d_s2_fwd_stats_zn", "convT_s2_fwd_stats", "conv2d_s2_dgrad", "convT_s2_dgrad", "conv2d_s2_wgrad",
             "convT_s2_wgrad", "convT_s1_tanh_fwd", "convT_s1_tanh_fwd_z16", "convT_s1_tanh_bwd", "instnorm_stats", "instnorm_apply", "instnorm_bwd",
-            "dense_fwd", "dense_wgrad", "heads_fwd", "heads_dgrad", "heads_wgrad"]
+            "dense_fwd", "dense_wgrad", "heads_fwd", "heads_dgrad", "heads_wgrad", "instnorm_bwd_coef", "convT_s2_dgrad_bn"]
 
 
 class _LazyStats:
@@ -53,6 +53,9 @@ def _snap(v):
         return _LazyStats(v, 0, v.B)
     if isinstance(v, ops._MomentRows):
         return _LazyStats(v.m, v.lo, v.hi)
+    if isinstance(v, ops.NormPartials):   # the shared workspace is overwritten by the next fused launch: copy the records now
+        n = v.shape[0] * v.nparts * 2
+        return ("norm_partials", v.buf[:n * 8].detach().to("cpu", copy=True).view(torch.float64).reshape(v.shape[0], v.nparts, 2), v.alpha, v.shape)
     if torch.is_tensor(v):
         return v.detach().to("cpu", copy=True)
     if isinstance(v, (list, tuple)):
@@ -276,6 +279,39 @@ def check_call(rec, packs, stats=None):
             db = d.reshape(-1, C).sum(0)
             lim = 3e-6 * np.abs(d.reshape(-1, C)).sum(0).max()
             assert np.abs(_np(pk["db"]) - db).max() <= lim, (tag, "db", np.abs(_np(pk["db"]) - db).max(), lim)
+        return tag
+    if n == "instnorm_bwd_coef":
+        # the norm backward without its apply pass: per-sample coefficient records from the producer-fused sums
+        z, st, parts = a[0], _np(a[1]), a[2]
+        assert isinstance(parts, tuple) and parts[0] == "norm_partials"
+        S = parts[1].numpy().sum(1)
+        L = z[0].numel()
+        sigma = st[:, 1]
+        m1, m2 = S[:, 0] / L, S[:, 1] / L / ((sigma + EPS) * sigma)
+        co = _np(ret)
+        tag = f"{n}{tuple(z.shape)}"
+        for got, exp in ((co[:, 0] + co[:, 1], st[:, 0] + st[:, 4]), (co[:, 2], st[:, 2]), (co[:, 3], st[:, 3]), (co[:, 4] + co[:, 6], m1), (co[:, 5] + co[:, 7], m2)):
+            assert np.abs(got - exp).max() <= 1e-7 * np.abs(exp).max() + 1e-30, (tag, got, exp)
+        return tag
+    if n == "convT_s2_dgrad_bn":
+        # data gradient fed with the level's raw (z, g): dz = bf16(a (g' - m1 - c m2')) is formed while the halo is staged and never
+        # written; reference = the same rounding, then the conv on the rounded operand.  m1 is also checked against mean(g') here
+        # (the sums come from the producer's epilogue).
+        z, g, co, alpha, ch = _np(a[0]), _np(a[1]), _np(a[2]), a[3], a[5]
+        w, _ = _w(rec, packs, 4)
+        B = z.shape[0]
+        sh = (B,) + (1,) * (z.ndim - 1)
+        mu, aa, bb = (co[:, 0] + co[:, 1]).reshape(sh), co[:, 2].reshape(sh), co[:, 3].reshape(sh)
+        m1, m2 = (co[:, 4] + co[:, 6]).reshape(sh), (co[:, 5] + co[:, 7]).reshape(sh)
+        c32 = ((z.astype(np.float32) - co[:, 0].astype(np.float32).reshape(sh)) - co[:, 1].astype(np.float32).reshape(sh))
+        y32 = (co[:, 2].astype(np.float32).reshape(sh) * c32).astype(np.float32) + co[:, 3].astype(np.float32).reshape(sh)
+        gp = np.where(y32 > 0, g, alpha * g)
+        tag = f"{n}{tuple(ret[0].shape)}"
+        m1_ref = gp.reshape(B, -1).mean(1)
+        assert np.abs(m1.reshape(B) - m1_ref).max() <= 2e-6 * np.abs(gp).reshape(B, -1).mean(1).max() + 1e-12, (tag, "m1", m1.reshape(B), m1_ref)
+        dz = O.bf16_round(aa * (gp - m1 - (z - mu) * m2))
+        ref = O.conv_fwd(dz, w, 2)
+        _cmp(tag, _np(ret[0]), O.bf16_round(ref), dict(rms=2e-3, mx=3e-2))   # (operand bits flip where dz sits on a bf16 tie)
         return tag
     if n in ("conv2d_s2_dgrad", "convT_s2_dgrad"):
         if isinstance(ret, tuple):  # (gradient, fused first-pass sums of the next norm backward): the sums are checked

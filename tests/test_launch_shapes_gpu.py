@@ -613,3 +613,66 @@ def test_normalising_down_conv_at_the_adjuster_batch(ops, layer):
         zc, sc = ops.conv2d_s2_fwd_stats_zn(zin16[lo:lo + CHUNK].contiguous(), st_in[lo:lo + CHUNK].contiguous(), ALPHA, pack, bias, cs, 1,
                                             gm, bt)
         assert torch.equal(zc, z[lo:lo + CHUNK]) and torch.equal(sc, st[lo:lo + CHUNK]), lo
+
+
+@pytest.mark.parametrize("layer,B", [("dec.conv4", 512), ("dec.conv3", 512), ("dec.conv4", 256), ("dec.conv3", 96)])
+def test_backward_normalising_data_gradient_at_the_adjuster_batch(ops, layer, B):
+    """lg_convT_s2_dgrad_bn at the sizes the step launches it (the Adjuster's decoder chain at 2B = 512, eager_trainer.py:158-163;
+    the Generator's on partition steps at B = 256): the data gradient fed with the level's RAW pair (z16, g16) + the per-sample
+    coefficients of lg_instnorm_bwd_coef == lg_instnorm_leaky_bwd_z16_p (apply pass writing dz16) followed by lg_convT_s2_dgrad_nf,
+    BIT FOR BIT: gradient AND the fused sums of the level below — that second path is the one
+    test_fused_data_gradient_and_norm_backward checks against the oracle.  32-image chunks equal the big launch (the coefficient record
+    is picked per item; samples carry different statistics), and dz against the oracle on sampled images through the chain."""
+    _, _, cb, cs, s = next(l for l in LAYERS if l[0] == layer)
+    w = _rand((5, 5, cb, cs), 61, 0.05)
+    pack = ops.conv_pack(w, cb, cs, 1)
+    shape = (B, 2 * s, 2 * s, cb)
+    z = _rand(shape, 62, 1.0) * (0.5 + 2.0 * torch.rand(B, 1, 1, 1, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7)))
+    z16 = (z + _rand((B, 1, 1, 1), 63, 1.0)).to(torch.bfloat16)
+    del z
+    g16 = _rand(shape, 64, 1.0).to(torch.bfloat16)
+    gm, bt = torch.tensor([0.9], device="cuda"), torch.tensor([0.15], device="cuda")
+    st = ops.instnorm_stats(z16.float(), gm, bt, 0, ALPHA)
+    zl16 = _rand((B, s, s, cs), 65, 1.3).add_(0.2).to(torch.bfloat16)          # the level below: raw output + statistics
+    stl = ops.instnorm_stats(zl16.float(), torch.tensor([1.1], device="cuda"), torch.tensor([-0.05], device="cuda"), 0, ALPHA)
+    assert ops.convT_s2_dgrad_bn_supported(B, s, s, cb, cs, 1)
+
+    def reference(lo, hi, parts):
+        dz16 = torch.empty((hi - lo,) + shape[1:], dtype=torch.bfloat16, device="cuda")
+        ops.instnorm_bwd(z16[lo:hi], st[lo:hi], g16[lo:hi], None, None, 0, 1, ALPHA, out16=dz16, want_f32=False, partials=parts)
+        gl, pl = ops.convT_s2_dgrad(None, pack, cs, 1, dy16=dz16, out_bf16=True, fuse=(zl16[lo:hi], stl[lo:hi], ALPHA))
+        return dz16, gl, pl
+
+    # sums {sum g', sum g' c} per (sample, part) as a producer would leave them ([B][4][2] doubles): here from a torch reduction
+    zz, gg = z16.double().reshape(B, 4, -1), g16.double().reshape(B, 4, -1)
+    mu, a_, b_ = (st[:, 0].double() + st[:, 4].double()).view(B, 1, 1), st[:, 2].view(B, 1, 1), st[:, 3].view(B, 1, 1)
+    c32 = (z16.float().reshape(B, 4, -1) - st[:, 0].view(B, 1, 1)) - st[:, 4].view(B, 1, 1)
+    gp = torch.where(a_ * c32 + b_ > 0, gg, ALPHA * gg)
+    sums = torch.stack([gp.sum(-1), (gp * (zz - mu)).sum(-1)], -1).contiguous()
+    del zz, gg, c32, gp
+
+    def partials(lo, hi):
+        return ops.NormPartials(sums[lo:hi].contiguous().view(torch.uint8).reshape(-1), 4, ALPHA, (hi - lo,) + shape[1:])
+
+    P = partials(0, B)
+    dz_ref, g_ref, p_ref = reference(0, B, P)
+    sums_ref = p_ref.buf[:B * p_ref.nparts * 16].clone().view(torch.float64)
+    coef = ops.instnorm_bwd_coef(z16, st, P)
+    g_bn, p_bn = ops.convT_s2_dgrad_bn(z16, g16, coef, ALPHA, pack, cs, fuse=(zl16, stl, ALPHA))
+    assert "BWDNORM" in ops.last_kernel()
+    assert torch.equal(g_bn, g_ref)
+    assert p_bn.nparts == p_ref.nparts and torch.equal(p_bn.buf[:B * p_bn.nparts * 16].view(torch.float64), sums_ref)
+    del g_ref, sums_ref
+    # dz of the reference chain against the oracle on sampled images (so the bit-equality above is anchored)
+    idx = _samples(B)
+    dref = _norm_ref(_f64(z16[idx]).reshape(len(idx), -1), _f64(g16[idx]).reshape(len(idx), -1), _f64(st[idx]))
+    assert _rms(_f64(dz_ref[idx]).reshape(len(idx), -1), O.bf16_round(dref)) < 6e-4
+    ref = O.conv_fwd(_f64(dz_ref[idx]), O.bf16_round(_f64(w)), 2)
+    assert _rms(_f64(g_bn[idx]), O.bf16_round(ref)) < 6e-4
+    for lo in range(0, B, CHUNK):
+        Pc = partials(lo, lo + CHUNK)
+        cc = ops.instnorm_bwd_coef(z16[lo:lo + CHUNK], st[lo:lo + CHUNK].contiguous(), Pc)
+        assert torch.equal(cc, coef[lo:lo + CHUNK]), lo
+        gc, _ = ops.convT_s2_dgrad_bn(z16[lo:lo + CHUNK], g16[lo:lo + CHUNK], cc, ALPHA, pack, cs,
+                                      fuse=(zl16[lo:lo + CHUNK], stl[lo:lo + CHUNK].contiguous(), ALPHA))
+        assert torch.equal(gc, g_bn[lo:lo + CHUNK]), lo

@@ -655,9 +655,9 @@ def test_step_input_forming_kernels(ops, B, ka, kc):
     out = ops.concat_cols(dev(a), dev(c))
     assert np.array_equal(out.cpu().numpy(), np.concatenate([a, c], -1))
     t, u = ops.adj_conditions(dev(c), dev(c1))
-    t_ref = np.concatenate([c, c1], 0)
+    t_ref = np.concatenate([c, c1], 0).astype(np.float32)
     assert np.array_equal(t.cpu().numpy(), t_ref)
-    assert np.array_equal(u.cpu().numpy(), (t_ref + np.float32(1.0)) * np.float32(0.5))
+    assert np.array_equal(u.cpu().numpy(), (t_ref + np.float32(1.0)) * np.float32(0.5))   # fp32 add, fp32 multiply
 
 
 @pytest.mark.parametrize("case", [(4, 8, 16, 64, 128, False), (3, 16, 16, 64, 128, True), (2, 8, 16, 128, 64, True), (6, 8, 8, 64, 128, False)])
