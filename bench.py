@@ -255,33 +255,28 @@ def main():
     b_next = b0 + a.warmup + a.steps + 100
     clock = None
     if world == 1 and not profiled:
-        # Shader clock HELD under this step, two ways (both after the timed region; d s_memtime / d s_memrealtime x 100 MHz):
-        #  (a) one probe wave resident on a side stream beside 20 further steps, 1-ms windows (lg_clock_probe; it ends when
-        #      lg_clock_stop raises its flag or when its time budget — the leg's expected length — is spent);
-        #  (b) a 20-us sampling wave on the COMPUTE stream right behind every conv-class launch of 5 further steps
-        #      (lg_clock_sample): the clock at those points of the step (the power controller moves it on a millisecond scale).
+        # Shader clock HELD under this step (after the timed region; d s_memtime / d s_memrealtime x 100 MHz):
+        #  (a) IN-KERNEL census: every block of the step's dominant kernel template (conv_down3, all its forms) adds the two counters'
+        #      increments over its own life (~100 us) to a buffer during 20 further steps (lg_set_clock_census) — the clock those
+        #      blocks ran at inside the real step;
+        #  (b) a 20-us sampling wave on the COMPUTE stream right behind every conv-class launch of 5 further steps (lg_clock_sample):
+        #      the clock an otherwise idle chip shows at those points — an upper bound, the power controller moves it within micro-
+        #      seconds of the load ending.  (A probe wave resident beside the step on a side stream reads 2.39 GHz whatever the other
+        #      CUs do — measured in round 4 against back-to-back convs, scripts/probe/clock_check.py — and is not used.)
         from littlegan_amd import _lib as lib
         L_ = lib.load()
-        ms_ref = dt / a.steps * 1e3
-        out5 = torch.zeros(5, dtype=torch.int64, device=device)
-        series = torch.zeros(2048, dtype=torch.int32, device=device)
-        flag = torch.zeros(1, dtype=torch.int32, device=device)
-        side = torch.cuda.Stream(device=device)
+        cen = torch.zeros(3, dtype=torch.int64, device=device)
         timed_steps(5, b_next)
-        with torch.cuda.stream(side):
-            lib.check(L_.lg_clock_probe(out5.data_ptr(), flag.data_ptr(), int(20 * ms_ref * 1.5) + 50, series.data_ptr(), series.numel(),
-                                        side.cuda_stream), "lg_clock_probe")
-        ms_clk = timed_steps(20, b_next + 5)
-        lib.check(L_.lg_clock_stop(flag.data_ptr(), torch.cuda.current_stream().cuda_stream), "lg_clock_stop")
-        torch.cuda.synchronize()
-        o = out5.tolist()
-        if o[1] > 0 and o[4] > 0:
-            w = sorted(series[:min(int(o[4]), series.numel())].tolist())
-            pick = lambda q: round(w[min(len(w) - 1, int(q * len(w)))] / 1e3, 1)
-            clock = {"mean_mhz": round(o[0] / o[1] * 100.0, 1), "p10_mhz": pick(0.10), "median_mhz": pick(0.50), "p90_mhz": pick(0.90),
-                     "min_window_mhz": round(o[2] / 1e3, 1), "max_window_mhz": round(o[3] / 1e3, 1),
-                     "windows_1ms": o[4], "leg_ms_per_step": round(ms_clk, 3),
-                     "method": "d s_memtime / d s_memrealtime x 100 MHz of one probe wave resident on a side stream beside 20 further steps (after the timed region)"}
+        lib.check(L_.lg_set_clock_census(cen.data_ptr()), "lg_set_clock_census")
+        try:
+            ms_clk = timed_steps(20, b_next + 5)
+        finally:
+            lib.check(L_.lg_set_clock_census(0), "lg_set_clock_census")
+        o = cen.tolist()
+        if o[1] > 0:
+            clock = {"in_kernel_mhz": round(o[0] / o[1] * 100.0, 1), "blocks": o[2], "kernel": "conv_down3_kernel (all forms)",
+                     "leg_ms_per_step": round(ms_clk, 3),
+                     "method": "sum d s_memtime / sum d s_memrealtime x 100 MHz over the block lives of the step's dominant kernel template, 20 further steps after the timed region"}
         out3 = torch.zeros(3, dtype=torch.int64, device=device)
         ops.Profile.start()
         ops.Profile.after_conv = lambda: lib.check(L_.lg_clock_sample(out3.data_ptr(), 20, torch.cuda.current_stream().cuda_stream), "lg_clock_sample")
@@ -292,8 +287,8 @@ def main():
             ops.Profile.stop()
         o3 = out3.tolist()
         if o3[1] > 0:
-            clock = dict(clock or {}, in_stream_samples={"mean_mhz": round(o3[0] / o3[1] * 100.0, 1), "samples": o3[2], "leg_ms_per_step": round(ms_smp, 3),
-                                                          "method": "20-us sampling wave on the compute stream behind every conv-class launch of 5 further steps"})
+            clock = dict(clock or {}, after_conv_launches={"mean_mhz": round(o3[0] / o3[1] * 100.0, 1), "samples": o3[2], "leg_ms_per_step": round(ms_smp, 3),
+                                                             "method": "20-us sampling wave on the compute stream behind every conv-class launch of 5 further steps (upper bound: chip otherwise idle during the sample)"})
         b_next += 100
     contention = None
     ks = [int(k) for k in a.dp_contention.split(",")] if a.dp_contention else ([32] if (world == 1 and a.workload == "c3" and args.mfma_dtype == "bf16" and not profiled) else [])

@@ -300,6 +300,10 @@ int lg_contention_probe(float* dst, const float* src, long long n, int workgroup
  * series (optional, series_cap entries): kHz per window */
 int lg_clock_probe(unsigned long long* out5, const int* stop_flag, long long max_ms, unsigned* series, int series_cap, void* stream);
 int lg_clock_stop(int* stop_flag, void* stream);
+/* in-kernel clock census: while buf3 (3 x 64-bit, device memory, zeroed by the caller) is registered, every block of the kernels that
+ * support it (conv_down3: the step's dominant kernel) adds {d s_memtime, d s_memrealtime (100 MHz), 1} of its own life to it;
+ * nullptr switches it off */
+int lg_set_clock_census(unsigned long long* buf3);
 /* one wave on the COMPUTE stream that spins spin_us microseconds behind the previous kernel and ADDS {d s_memtime, d s_memrealtime, 1}
  * to out3: the clock the chip holds at that point of the step */
 int lg_clock_sample(unsigned long long* out3, int spin_us, void* stream);

@@ -77,6 +77,7 @@ struct D3Params {
   float nalpha;        //   ... and the operand is bf16(leaky(InstanceNorm(z))), formed while the halo is staged
   const __bf16* gsrc;  // NORM = 2 (BWDNORM): src is the raw output z of THIS level, gsrc the gradient g w.r.t. its normalised + activated
   const float* bcoef;  //   map, bcoef the per-sample records of lg_instnorm_bwd_coef: the operand dz is formed while the halo is staged
+  unsigned long long* clk;  // clock census (runtime.hip: lg_set_clock_census) or null
   int stagger;         // start delay of the odd-slot block in ~1024-cycle units
   unsigned long long* stamps;  // diagnostic build only (LG_D3_STAMPS): [block][64] s_memtime stamps of wave 0
   int stamp_lite;              // only the block's first / last stamp (the per-phase stamps cost ~11 % and change the clock)
@@ -110,12 +111,19 @@ constexpr int toff_bytes(int t) {  // tap t = ky*5+kx: LDS byte offset of its so
 // arithmetic and rounding, lg_bwdnorm8 — is formed per 16-B halo piece between the two buffer loads and the LDS store, so the
 // norm-backward apply pass and its dz tensor disappear (6 B per element of HBM traffic less; the piece loads double).  For tapes that
 // ask the level for no weight gradient: the Adjuster's decoder chain at 2B (eager_trainer.py:158-163), partition steps of the
-// Generator.  Bit-identical to bwd_apply16 + conv (tests/test_launch_shapes_gpu.py).  Weight ring of 5 at NW = 128 (register budget).
+// Generator.  Bit-identical to bwd_apply16 + conv (tests/test_launch_shapes_gpu.py).
+// Measured in the C3 step (round 4, same box, A/B by LG_NO_BWDNORM): the N = 64 level (convT4's data gradient at 2B = 512: apply pass
+// 303 us + conv 321 us -> 552 us) gains 72 us per launch; the N = 128 level (convT3: 150 + 222 -> 395 us) LOSES 23 — 17 VALU
+// operations per element, 1.3 x the elements (halo), land on a kernel that was matrix-bound, not HBM-bound — and is not instantiated.
+// Two compiler facts from the way: (1) the staging arithmetic must be pinned behind the tap loop (see commit below); (2) the per-item
+// coefficient record must be read through the constant address space (lg_as_const, lg_common.h): as a plain load hipcc made it a
+// VECTOR load inside the item loop, `s_waitcnt vmcnt(0)` at every item boundary — and that build was NOT deterministic with two
+// blocks per CU (one block per CU: deterministic; tests/diagnostics/bwdnorm_det.py), which the scalar-load build is.
 template <bool STATS, bool FUSE = false, bool PAIR = false, int NW = 128, int NORM = 0>
 __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   static_assert(!(STATS && FUSE), "forward moments and backward sums are never needed together");
   static_assert(NORM != 1 || (STATS && NW == 128 && !PAIR), "the normalising form exists for the forward passes with fused moments, 8 x 16 tiles");
-  static_assert(NORM != 2 || (!STATS && !PAIR), "the backward-normalising form exists for the data gradients on 8 x 16 tiles");
+  static_assert(NORM != 2 || (!STATS && !PAIR && NW == 64), "the backward-normalising form exists for the 64-column data gradients on 8 x 16 tiles");
   static_assert(NW == 128 || (NW == 64 && !PAIR), "tile widths");
   constexpr int NWV = NW / 32, NI = NW / 32;          // waves along the channels; 32-pixel groups per wave (4 | 2)
   constexpr int PPR = NW / 8, NQ = 128 * PPR / 256;   // 16-B pieces per output pixel row; pieces per thread in the row sweep
@@ -134,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   const int lb = lg_xcd_remap(blockIdx.x, G);
   const int nmine = (p.nitems - lb + G - 1) / G;
   const int total = nmine * nchunk;
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();   // clock census (see the end)
   // ---- the (up to) 6 halo pieces this thread stages in every slice: LDS offset and position inside the halo ----------
   int pl[PPT], pyx[PPT];
 #pragma unroll
@@ -189,11 +198,11 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   LgBwdCoef bco{};                                         // BWDNORM: the item's sample
   auto set_item = [&](const Item& it) __attribute__((always_inline)) {
     if constexpr (NORM == 1) {
-      const float* sp = p.nstats + (long long)it.n * 8;   // uniform: scalar loads
+      const lg_const_f32p sp = lg_as_const(p.nstats + (long long)it.n * 8);   // uniform + constant space: scalar loads
       nmu0 = sp[0]; nna0 = sp[2]; nnb0 = sp[3]; nml0 = sp[4];
     }
     if constexpr (NORM == 2) {
-      const float* sp = p.bcoef + (long long)it.n * 8;    // uniform: one 32-byte scalar load
+      const lg_const_f32p sp = lg_as_const(p.bcoef + (long long)it.n * 8);    // uniform + constant space: one 32-byte scalar load
       bco.mu = sp[0]; bco.mul = sp[1]; bco.a = sp[2]; bco.b = sp[3]; bco.m1 = sp[4]; bco.m2 = sp[5]; bco.m1l = sp[6]; bco.m2l = sp[7];
     }
 #pragma unroll
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   // Weight-fragment ring: RING fragments (= taps) ahead of the MFMAs.  25 taps per slice and RING = 10 -> the ring
   // position of tap 0 alternates between 0 and 5 from one slice to the next: the slice body exists in two copies
   // (OFF = 0 / 5) so that every ring access is a compile-time register.
-  constexpr int RING = (NORM == 2 && NW == 128) ? 5 : LG_D3_RING;   // (r2 A/B: a 5-tap ring is within +-3 % of the 10-tap one, 20 VGPRs less)
+  constexpr int RING = LG_D3_RING;
   constexpr int AD = LG_D3_ADEPTH;
   u32x4 bf[RING];
   u32x4 hv[PPT];
@@ -374,6 +383,10 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
       }
     }
     D3_STAMP();   // taps done
+    // NORM forms: the staging arithmetic stays BEHIND the tap loop.  Left free, hipcc hoists its first unpacking shifts into the first
+    // taps of the slice, and with them an `s_waitcnt vmcnt(2)` for the halo pieces requested a few instructions earlier: every slice
+    // then opens by sitting out the HBM latency of its own prefetch (seen in the .s of the BWDNORM form, round 4).
+    if constexpr (NORM != 0) __builtin_amdgcn_sched_barrier(0);
     commit(smem + ((s + 1) & 1) * HB, hv);
     __syncthreads();  // slice s consumed by every wave, slice s+1 complete
     D3_STAMP();   // barrier passed
@@ -453,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
         *reinterpret_cast<u32x4*>(p.out + goff) = v;
         if constexpr (FUSE) {
           // PAIR: the tile column of a thread's pieces is fixed ((tid >> 4) & 15): waves 0, 1 sweep sample n, waves 2, 3 n + 1
-          const float* sp = p.nf.stats + (long long)(cur.n + (PAIR ? wid >> 1 : 0)) * 8;
+          const lg_const_f32p sp = lg_as_const(p.nf.stats + (long long)(cur.n + (PAIR ? wid >> 1 : 0)) * 8);   // scalar loads (lg_common.h)
           lg_nf_accum(v, zq[q8], sp[0], sp[4], sp[2], sp[3], p.nf.alpha, nf1, nf2);
         }
       }
@@ -520,6 +533,12 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
       if (s + 1 < total) slice(std::integral_constant<int, NTAP % RING>{}, s + 1);
     }
   }
+  if (p.clk && wid == 0 && lane == 0) {   // one lane per block: three no-return adds at the end of a ~100-us block life
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (t1 > clk_t0 && r1 > clk_r0) {
+      atomicAdd(p.clk, t1 - clk_t0); atomicAdd(p.clk + 1, r1 - clk_r0); atomicAdd(p.clk + 2, 1ull);
+    }
+  }
 #ifdef LG_D3_STAMPS
   if (p.stamps && wid == 0 && lane == 0) {
     p.stamps[(long long)blockIdx.x * 64 + 60] = __builtin_amdgcn_s_memtime();
@@ -563,9 +582,9 @@ extern "C" int lg_conv_down3_zn_supported(int B, int Hm, int Wm, int Cs, int N) 
 // sums of the NEXT level's norm backward are always fused (nf), 8 x 16 tiles only; LG_ERR_UNSUPPORTED otherwise.
 extern "C" int lg_conv_down3_bn_supported(int B, int Hm, int Wm, int Cs, int N) {
   const bool pair = Hm == 8 && Wm == 8 && B % 2 == 0;
-  // N = 128 x k with k > 1: every column tile would redo the dz arithmetic of the halo it shares — measured for the forward
-  // normalising form (conv3: + 30 us of 197), not built for the backward one
-  return (!lg_env_flag("LG_NO_D3_BWDNORM") && !pair && Hm % TH == 0 && Wm % TW == 0 && (N == 64 || N == 128) &&
+  // N = 64 only: at N = 128 the form was built and measured slower than apply pass + conv (kernel header); with more than one column
+  // tile every tile would redo the dz arithmetic of the halo it shares
+  return (!lg_env_flag("LG_NO_D3_BWDNORM") && !pair && Hm % TH == 0 && Wm % TW == 0 && N == 64 &&
           lg_conv_down3_supported(B, Hm, Wm, Cs, N)) ? 1 : 0;
 }
 extern "C" int lg_conv_down3_bn_try(const void* z16, const void* g16, const float* bcoef, float alpha, const void* wpack, void* out16,
@@ -604,9 +623,10 @@ static int down3_launch(const void* src16, const void* wpack, const float* bias,
   p.spart = stats ? (double*)spart : nullptr;
   if (fuse) p.nf = *nf;
   if (nstats && (!stats || n64 || pair)) return LG_ERR_UNSUPPORTED;
-  if (g16 && (!fuse || pair || nstats || p.ntn != 1)) return LG_ERR_UNSUPPORTED;
+  if (g16 && (!fuse || pair || nstats || !n64 || p.ntn != 1)) return LG_ERR_UNSUPPORTED;
   p.nstats = nstats; p.nalpha = nalpha;
   p.gsrc = (const __bf16*)g16; p.bcoef = bcoef;
+  p.clk = lg_clock_census();
   static int bpc = 0;   // resident blocks per CU
   if (!bpc) {
     bpc = 2;
@@ -621,7 +641,6 @@ static int down3_launch(const void* src16, const void* wpack, const float* bias,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, false, false, 64>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, true, false, 64>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<true, false, false, 128, 1>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, true, false, 128, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>((conv_down3_kernel<false, true, false, 64, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, D3L<false>::LDS_BYTES);
   }
   const int nblk = bpc * lg_grid_cus();   // every block resident from the start, also beside communication kernels (runtime.hip)
@@ -631,8 +650,7 @@ static int down3_launch(const void* src16, const void* wpack, const float* bias,
   if (nstats) {
     hipLaunchKernelGGL((conv_down3_kernel<true, false, false, 128, 1>), dim3(grid), dim3(256), LDS0, st, p);
   } else if (g16) {
-    if (n64) hipLaunchKernelGGL((conv_down3_kernel<false, true, false, 64, 2>), dim3(grid), dim3(256), LDS0, st, p);
-    else hipLaunchKernelGGL((conv_down3_kernel<false, true, false, 128, 2>), dim3(grid), dim3(256), LDS0, st, p);
+    hipLaunchKernelGGL((conv_down3_kernel<false, true, false, 64, 2>), dim3(grid), dim3(256), LDS0, st, p);
   } else if (pair) {
     if (fuse) hipLaunchKernelGGL((conv_down3_kernel<false, true, true>), dim3(grid), dim3(256), LDS1, st, p);
     else if (stats) hipLaunchKernelGGL((conv_down3_kernel<true, false, true>), dim3(grid), dim3(256), LDS1, st, p);
@@ -645,7 +663,7 @@ static int down3_launch(const void* src16, const void* wpack, const float* bias,
   else if (stats) hipLaunchKernelGGL(conv_down3_kernel<true>, dim3(grid), dim3(256), LDS0, st, p);
   else hipLaunchKernelGGL(conv_down3_kernel<false>, dim3(grid), dim3(256), LDS0, st, p);
   LG_CHECK_LAUNCH("lg_conv_down3");
-  lg_note_kernel(g16 ? (n64 ? "conv_down3_kernel<NW=64,BWDNORM>" : "conv_down3_kernel<NW=128,BWDNORM>") : nstats ? "conv_down3_kernel<NW=128,NORM>" : pair ? "conv_down3_kernel<PAIR>" : n64 ? "conv_down3_kernel<NW=64>" : "conv_down3_kernel<NW=128>");
+  lg_note_kernel(g16 ? "conv_down3_kernel<NW=64,BWDNORM>" : nstats ? "conv_down3_kernel<NW=128,NORM>" : pair ? "conv_down3_kernel<PAIR>" : n64 ? "conv_down3_kernel<NW=64>" : "conv_down3_kernel<NW=128>");
   if (stats || fuse) *nparts_out = p.nparts;
   return LG_OK;
 }

@@ -435,7 +435,7 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
         if (tl) *reinterpret_cast<u32x4*>(p.out + goff) = v;
         if constexpr (FUSE) {
           if (tl) {
-            const float* sp = p.nf.stats + (long long)tn_ * 8;
+            const lg_const_f32p sp = lg_as_const(p.nf.stats + (long long)tn_ * 8);   // scalar loads (lg_common.h)
             lg_nf_accum(v, zq[q8], sp[0], sp[4], sp[2], sp[3], p.nf.alpha, nf1, nf2);
           }
         }

@@ -24,6 +24,7 @@ extern "C" void lg_set_error(const char* fmt, ...);
 // Names the kernel template a conv / weight-gradient entry point has just launched (thread-local, static strings only):
 // bench.py reads it back through lg_last_kernel() so that its roofline line names a KERNEL, not a class of kernels.
 extern "C" void lg_note_kernel(const char* name);
+extern "C" unsigned long long* lg_clock_census(void);   // runtime.hip: buffer of the in-kernel clock census, or null
 
 // 1 if the environment variable is set to a non-empty value; read ONCE per process at its first use (runtime.hip), so a
 // *_supported query and the launch it promises always agree.  `name` must be a string literal.
@@ -146,6 +147,14 @@ __device__ __forceinline__ u32x4 lg_norm8(const u32x4 z8, float mu, float mul, f
   }
   return o;
 }
+
+// Per-item records read inside a persistent loop (statistics, norm-backward coefficients: written by an EARLIER kernel, constant
+// for this one): read through the constant address space.  A plain uniform load there is scalarised by hipcc only while it can
+// prove that no store of the kernel may alias it — true in the prologue, false inside the item loop behind the output stores — and
+// otherwise becomes a VECTOR load whose value is needed at once: `s_waitcnt vmcnt(0)` at every item boundary, which also drains the
+// weight-fragment ring (seen in the .s of conv_down3's normalising forms, round 4).  From the constant space it is an s_load.
+typedef const float __attribute__((address_space(4)))* lg_const_f32p;
+__device__ __forceinline__ lg_const_f32p lg_as_const(const float* p) { return (lg_const_f32p)(p); }
 
 // 8 bf16 z, 8 bf16 g -> 8 bf16 dz of the InstanceNorm + LeakyReLU backward, exactly bwd_apply16_kernel (norm.hip) in its
 // post-LeakyReLU form: c = (z - mu) - mul; g' = (a c + b > 0) ? g : alpha g; dz = a ((((g' - m1) - m1l) - c m2) - c m2l); RNE.

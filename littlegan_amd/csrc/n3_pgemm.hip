@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict_
           *reinterpret_cast<bf16x8*>(out16 + o0 + idx * 8) = v;
           if constexpr (FUSE) {
             const u32x4 zq = *reinterpret_cast<const u32x4*>(nf.z + o0 + idx * 8);
-            const float* sp = nf.stats + (long long)n * 8;
+            const lg_const_f32p sp = lg_as_const(nf.stats + (long long)n * 8);   // scalar loads (lg_common.h)
             lg_nf_accum(__builtin_bit_cast(u32x4, v), zq, sp[0], sp[4], sp[2], sp[3], nf.alpha, nf1, nf2);
           }
         }

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, XJ == 2 ? 2 : 1) void s1t_fwd_rows_kernel(cons
   for (int k = 0; k < VW; ++k) bl[k] = bias[(lane * VW + k) % 3];
   float mu = 0.f, mul = 0.f, na = 1.f, nb = 0.f;
   if constexpr (NORM) {
-    const float* sp = ni.stats + (long long)n * 8;
+    const lg_const_f32p sp = lg_as_const(ni.stats + (long long)n * 8);   // scalar loads (lg_common.h)
     mu = sp[0]; na = sp[2]; nb = sp[3]; mul = sp[4];
   }
   // staging geometry: piece q = lane + 64k of the SP-pixel row -> pixel p, 16-B piece j.  The row is fetched with raw

@@ -15,6 +15,7 @@
 #include "../../include/littlegan_hip.h"
 
 static int g_reserved_cus = 0;
+static unsigned long long* g_clock_census = nullptr;
 
 static int device_cus() {
   static int cus = 0;
@@ -153,3 +154,11 @@ extern "C" int lg_clock_stop(int* stop_flag, void* stream) {
   LG_CHECK_LAUNCH("lg_clock_stop");
   return LG_OK;
 }
+
+// In-kernel clock census (bench.py's `clock` field): while a buffer is registered, every block of the persistent conv kernels that
+// support it (conv_down3.hip: the dominant kernel of the step) adds, at its end, {d s_memtime, d s_memrealtime, 1} of its own life to
+// buf3 — sum[0] / sum[1] x 100 MHz is the shader clock those blocks saw WHILE THEY RAN in the real step.  (A probe wave that sits
+// beside the step on a side stream does not see it: measured in round 4, it reads 2.39 GHz whatever the other CUs do, while a
+// sampling wave right behind back-to-back convs reads 2.14.)  nullptr = off (the default; two scalar instructions per block remain).
+extern "C" int lg_set_clock_census(unsigned long long* buf3) { g_clock_census = buf3; return LG_OK; }
+extern "C" unsigned long long* lg_clock_census(void) { return g_clock_census; }

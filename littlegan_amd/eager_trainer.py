@@ -360,15 +360,28 @@ class EagerTrainer:
         npz = os.path.join(tdir, "test_data_" + str(getattr(a, "env", "default")) + ".npz") if tdir else None
 
         def usable(path):
-            """a complete file of THIS configuration (the reference regenerates when the shapes do not fit, :77-80)"""
+            """a complete file whose shapes the models accept (the reference loads whatever batch count the file holds and regenerates
+            only when G / D / A reject its shapes, :69-83): noise_dim, cond_dim, H, W, C must fit; n, c, i share one leading
+            dimension, which need NOT be args.batch_size (a file written under another batch size, or from a short first batch)."""
             try:
                 with np.load(path) as d:
                     n, c, i = d["n"], d["c"], d["i"]
-                H = a.init_dim * 16
-                return (n.shape == (a.batch_size, a.noise_dim) and c.shape == (a.batch_size, a.cond_dim)
-                        and i.shape == (a.batch_size, H, H, a.image_channel))
-            except Exception:
+            except Exception as e:
+                print(f"test data {path}: unreadable ({e}); regenerating")
                 return False
+            H = a.init_dim * 16
+            why = None
+            if n.ndim != 2 or n.shape[1] != a.noise_dim:
+                why = f"noise {n.shape} does not fit noise_dim {a.noise_dim}"
+            elif c.ndim != 2 or c.shape[1] != a.cond_dim:
+                why = f"cond {c.shape} does not fit cond_dim {a.cond_dim}"
+            elif i.ndim != 4 or tuple(i.shape[1:]) != (H, H, a.image_channel):
+                why = f"image {i.shape} does not fit {H}x{H}x{a.image_channel}"
+            elif not (n.shape[0] == c.shape[0] == i.shape[0] and n.shape[0] > 0):
+                why = f"n, c, i hold {n.shape[0]}, {c.shape[0]}, {i.shape[0]} samples"
+            if why:
+                print(f"test data {path}: {why}; regenerating")
+            return why is None
 
         # data parallel: ONE decision for all ranks (rank 0 looks, the others are told) — a rank that finds rank 0's half-
         # written file, or loads while others generate, would leave the dataset generators of the ranks one draw apart
@@ -381,10 +394,15 @@ class EagerTrainer:
             data = np.load(npz)
             to = lambda v: torch.tensor(np.asarray(v, np.float32), device=self.device)
             self.test_noise, self.test_cond, self.test_image = to(data["n"]), to(data["c"]), to(data["i"])
-            if self.dataset is not None:
-                self.dataset.get_new_iterator()   # the generating path draws one epoch order: keep every path's generator in step
+            if self.dataset is not None and self.world > 1:
+                # data parallel only: the generating path draws one epoch order — keep every rank's (and every path's) dataset
+                # generator in step.  A single process does not draw (the reference does not on reuse, :69-76).
+                self.dataset.get_new_iterator()
             return
         if self.dataset is None:
+            if getattr(a, "reuse", False) and npz:   # dataset-less modes (condition-sample, export-model): say so, they do not evaluate
+                print(f"No fixed evaluation batch: {npz} is missing or does not fit this configuration and there is no dataset to draw "
+                      "one from (test_noise / test_cond / test_image stay None)")
             return
         print("No reuse test data, generating...")
         it = self.dataset.get_new_iterator()

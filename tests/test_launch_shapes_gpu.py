@@ -615,7 +615,7 @@ def test_normalising_down_conv_at_the_adjuster_batch(ops, layer):
         assert torch.equal(zc, z[lo:lo + CHUNK]) and torch.equal(sc, st[lo:lo + CHUNK]), lo
 
 
-@pytest.mark.parametrize("layer,B", [("dec.conv4", 512), ("dec.conv3", 512), ("dec.conv4", 256), ("dec.conv3", 96)])
+@pytest.mark.parametrize("layer,B", [("dec.conv4", 512), ("dec.conv4", 256), ("dec.conv4", 96)])
 def test_backward_normalising_data_gradient_at_the_adjuster_batch(ops, layer, B):
     """lg_convT_s2_dgrad_bn at the sizes the step launches it (the Adjuster's decoder chain at 2B = 512, eager_trainer.py:158-163;
     the Generator's on partition steps at B = 256): the data gradient fed with the level's RAW pair (z16, g16) + the per-sample
@@ -636,6 +636,7 @@ def test_backward_normalising_data_gradient_at_the_adjuster_batch(ops, layer, B)
     zl16 = _rand((B, s, s, cs), 65, 1.3).add_(0.2).to(torch.bfloat16)          # the level below: raw output + statistics
     stl = ops.instnorm_stats(zl16.float(), torch.tensor([1.1], device="cuda"), torch.tensor([-0.05], device="cuda"), 0, ALPHA)
     assert ops.convT_s2_dgrad_bn_supported(B, s, s, cb, cs, 1)
+    assert not ops.convT_s2_dgrad_bn_supported(B, 32, 32, 64, 128, 1)   # the 128-column level: measured slower than apply + conv, not built
 
     def reference(lo, hi, parts):
         dz16 = torch.empty((hi - lo,) + shape[1:], dtype=torch.bfloat16, device="cuda")

@@ -82,6 +82,16 @@ def test_fixed_evaluation_batch_is_created_then_reused(tmp_path):
     assert np.array_equal(tr2.test_image.cpu().numpy(), data["i"])
     tr3 = _trainer(_small_args(tmp_path, reuse=False))
     assert np.array_equal(tr3.test_noise.cpu().numpy(), data["n"])
+    # a file holding ANOTHER batch count is loaded as it is (the reference loads whatever the file holds, :69-76) ...
+    np.savez_compressed(npz, n=data["n"][:3], c=data["c"][:3], i=data["i"][:3])
+    tr4 = _trainer(_small_args(tmp_path, reuse=True))
+    assert tr4.test_noise.shape[0] == 3 and np.array_equal(tr4.test_image.cpu().numpy(), data["i"][:3])
+    # ... one whose shapes the models reject is regenerated (:77-83) and rewritten
+    np.savez_compressed(npz, n=data["n"][:, :4], c=data["c"], i=data["i"])
+    tr5 = _trainer(_small_args(tmp_path, reuse=True))
+    assert np.array_equal(tr5.test_noise.cpu().numpy(), data["n"])
+    with np.load(npz) as f:
+        assert f["n"].shape == (4, 5)
     # the reference attribute names of SURVEY.md par. 8b exist and alias the trained weights
     D = tr.discriminator
     assert D.dense_pr.kernel.data_ptr() == D.weights[16].data_ptr() and D.dense_cond.bias.data_ptr() == D.weights[19].data_ptr()

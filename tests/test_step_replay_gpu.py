@@ -42,10 +42,10 @@ def test_every_call_of_a_full_step_matches_the_oracle(mfma, init_dim):
     assert zn == ((1 if init_dim == 4 else 2) if mfma == "bf16" else 0)
     assert seen["convT_s2_fwd_stats"] == 8 and seen["conv2d_s2_fwd_stats"] + zn == 12
     # disc tape 4 + gen tape 4 + adj tape 4 encoder levels, G tape 4 + adj tape 4 decoder levels, 2 dense norms — in the bf16 path the
-    # Adjuster's decoder levels 4 and 3 (no weight gradient asked: eager_trainer.py:163) leave the norm-backward apply to the
-    # data-gradient conv below them (lg_convT_s2_dgrad_bn): a coefficient launch instead of instnorm_bwd, dgrad_bn instead of dgrad
+    # Adjuster's decoder level 4 (no weight gradient asked: eager_trainer.py:163) leaves the norm-backward apply to the data-gradient
+    # conv below it (lg_convT_s2_dgrad_bn, the 64-column level): a coefficient launch instead of instnorm_bwd, dgrad_bn instead of dgrad
     bn = seen.get("convT_s2_dgrad_bn", 0)
-    assert bn == (2 if mfma == "bf16" else 0) and seen.get("instnorm_bwd_coef", 0) == bn
+    assert bn == (1 if mfma == "bf16" else 0) and seen.get("instnorm_bwd_coef", 0) == bn
     assert seen["instnorm_bwd"] == 22 - bn
     assert seen["conv2d_s2_wgrad"] == 4 and seen["convT_s2_wgrad"] == 4 and seen["convT_s1_tanh_bwd"] == 2
     assert seen["conv2d_s2_dgrad"] == 3 + 4 + 4 and seen["convT_s2_dgrad"] + bn == 4 + 4
