@@ -51,6 +51,7 @@ struct U4Params {
   int B, Hs, Ws, Cs, N, N32, KB;
   int tpi_x, tpi, ntn, nper, nparts;   // nper = items per class
   int gend[4];         // block ranges: class rank rk (taps 9, 6, 6, 4) owns blocks [gend[rk-1], gend[rk])
+  int pairmode;        // 1 (default): blocks [0, gend[0]) run classes 3 then 0, blocks [gend[0], gend[1]) classes 1 then 2 (see the kernel)
   LgNormFuse nf;
 };
 
@@ -364,6 +365,24 @@ __global__ __launch_bounds__(256, 2) void conv_up4_kernel(const U4Params p) {
   static_assert(!(STATS && FUSE), "forward moments and backward sums are never needed together");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x;  // (uniform) class of this block: rank 0..3 = classes 3, 1, 2, 0
+  // CLASS PAIRS (round 4): with one class per block the four classes' item counts are equal but their lengths are 9 : 6 : 6 : 4 taps,
+  // and whole items cannot be dealt 9 : 6 : 6 : 4 over 512 slots — at B = 256 the 8 x 8 level has 256 items per class: the 9-tap
+  // blocks take 2 items (18 tap units) or 1, the 6-tap ones 3 or 2, the 4-tap ones 4 or 3, and the launch lasts 18 units against a
+  // mean of 12.5 (16 x 16 level: 30 against 25).  A block bound to the class PAIR (3, 0) or (1, 2) runs two persistent loops back to
+  // back — still ONE slice body per loop, so no register growth — and a pair is 13 or 12 tap units: 256 + 256 blocks take exactly
+  // one item of each of their classes.  Measured: see DESIGN 10.
+  if (p.pairmode) {
+    if (b < p.gend[0]) {
+      up4_run<3, STATS, FUSE, PAIR>(p, smem, b, p.gend[0]);
+      __syncthreads();
+      up4_run<0, STATS, FUSE, PAIR>(p, smem, b, p.gend[0]);
+    } else {
+      up4_run<1, STATS, FUSE, PAIR>(p, smem, b - p.gend[0], p.gend[1] - p.gend[0]);
+      __syncthreads();
+      up4_run<2, STATS, FUSE, PAIR>(p, smem, b - p.gend[0], p.gend[1] - p.gend[0]);
+    }
+    return;
+  }
   if (b < p.gend[0]) up4_run<3, STATS, FUSE, PAIR>(p, smem, b, p.gend[0]);
   else if (b < p.gend[1]) up4_run<1, STATS, FUSE, PAIR>(p, smem, b - p.gend[0], p.gend[1] - p.gend[0]);
   else if (b < p.gend[2]) up4_run<2, STATS, FUSE, PAIR>(p, smem, b - p.gend[1], p.gend[2] - p.gend[1]);
@@ -417,6 +436,25 @@ extern "C" int lg_conv_up4_nf_try(const void* src16, const void* wpack_up, const
   }
   // the grid is split between the classes in proportion to their tap counts (9 : 6 : 6 : 4), at most one block per item
   int grid = 0;
+  static int classpair = -1;
+  if (classpair < 0) classpair = lg_env_flag("LG_U4_NO_CLASSPAIR") ? 0 : 1;
+  p.pairmode = classpair;
+  if (classpair) {
+    // blocks of type A run classes (3, 0): 13 tap units per item pair; type B classes (1, 2): 12.  GA + GB <= nblk, each <= nper:
+    // the split with the smallest makespan max(ceil(nper / GA) * 13, ceil(nper / GB) * 12); ties go to the split with fewer idle slots.
+    long long best = -1;
+    int ga_best = 1, gb_best = 1;
+    for (int ga = 1; ga < nblk && ga <= p.nper; ++ga) {
+      int gb = nblk - ga;
+      if (gb > p.nper) gb = p.nper;
+      if (gb < 1) break;
+      const long long ca = (long long)((p.nper + ga - 1) / ga) * 13, cb = (long long)((p.nper + gb - 1) / gb) * 12;
+      const long long cost = (ca > cb ? ca : cb) * 4096 - (ga + gb);   // makespan first, then as many blocks as fit
+      if (best < 0 || cost < best) { best = cost; ga_best = ga; gb_best = gb; }
+    }
+    p.gend[0] = ga_best; p.gend[1] = ga_best + gb_best; p.gend[2] = p.gend[3] = p.gend[1];
+    grid = ga_best + gb_best;
+  } else
   {
     const int taps[4] = {9, 6, 6, 4};
     int left = nblk;

@@ -26,7 +26,8 @@ for name, Hs, cb, cs in LAYERS:
     pack = ops.conv_pack(w, cb, cs, 1)
     x16 = torch.randn(B, Hs, Hs, cs, device="cuda", generator=g).to(torch.bfloat16)   # random data (guide rule 25)
     bias = torch.randn(cb, device="cuda", generator=g) * 0.1
-    fns.append(lambda pack=pack, x16=x16, bias=bias, cb=cb: ops.convT_s2_fwd_stats(None, pack, bias, cb, 1, gm, bt, x16=x16, z16=True))
+    # defer_stats=True: as the step launches them — the moment partials are finished inside the following apply launch, not by a launch of their own
+    fns.append(lambda pack=pack, x16=x16, bias=bias, cb=cb: ops.convT_s2_fwd_stats(None, pack, bias, cb, 1, gm, bt, x16=x16, z16=True, defer_stats=True))
     flops.append(50.0 * B * Hs * Hs * cb * cs)
     names.append(name)
 w = torch.randn(5, 5, 3, 32, device="cuda", generator=g) * 0.05
