@@ -78,6 +78,7 @@ struct D3Params {
   const __bf16* gsrc;  // NORM = 2 (BWDNORM): src is the raw output z of THIS level, gsrc the gradient g w.r.t. its normalised + activated
   const float* bcoef;  //   map, bcoef the per-sample records of lg_instnorm_bwd_coef: the operand dz is formed while the halo is staged
   unsigned long long* clk;  // clock census (runtime.hip: lg_set_clock_census) or null
+  int lds_order;       // 1: halo pieces dealt to the threads in LDS order (the round-2 map; LG_D3_LDS_ORDER, A/B), 0: in memory order
   int stagger;         // start delay of the odd-slot block in ~1024-cycle units
   unsigned long long* stamps;  // diagnostic build only (LG_D3_STAMPS): [block][64] s_memtime stamps of wave 0
   int stamp_lite;              // only the block's first / last stamp (the per-phase stamps cost ~11 % and change the clock)
@@ -158,6 +159,24 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
       } else {
         const int hx = hxp < HWH ? 2 * hxp : 2 * (hxp - HWH) + 1;
         pyx[u] = hx < 2 * TW + 3 ? (hy << 8) | hx : (0x7fff << 8);  // the 36th slot of a row is padding: never valid
+      }
+    }
+    if constexpr (!PAIR) {
+      // GLOBAL-ORDER pieces (round 4; p.lds_order = 1 restores the LDS-order map above for A/B): consecutive lanes take consecutive
+      // 16-B pieces of the source in MEMORY order — (pixel x, half 0), (x, half 1), (x + 1, half 0), ... along a halo row — and write
+      // them to their de-interleaved LDS slots.  In LDS order a wave's 64 pieces are 32 pixels two columns apart: for the 32-channel
+      // source of the N = 64 level (64 B per pixel) every load instruction touched 32 cache lines and used a quarter of each; in
+      // memory order it touches 16 and uses half (the other half is the next slice).  The padding slot of a row is never read
+      // (largest slot a tap reaches: 34) and no longer written.
+      if (!p.lds_order) {
+        constexpr int PPROW = 2 * (2 * TW + 3);   // 70 real pieces per halo row
+        pl[u] = -1; pyx[u] = (0x7fff << 8);
+        if (q < HH * PPROW) {
+          const int hy = q / PPROW, rem = q - hy * PPROW, hx = rem >> 1;
+          const int hxp = (hx & 1) ? HWH + (hx >> 1) : (hx >> 1);
+          pl[u] = (hy * HWP + hxp) * ROWB + (rem & 1) * 16;
+          pyx[u] = (hy << 8) | hx;
+        }
       }
     }
   }
@@ -627,6 +646,7 @@ static int down3_launch(const void* src16, const void* wpack, const float* bias,
   p.nstats = nstats; p.nalpha = nalpha;
   p.gsrc = (const __bf16*)g16; p.bcoef = bcoef;
   p.clk = lg_clock_census();
+  p.lds_order = lg_env_flag("LG_D3_LDS_ORDER") ? 1 : 0;
   static int bpc = 0;   // resident blocks per CU
   if (!bpc) {
     bpc = 2;
