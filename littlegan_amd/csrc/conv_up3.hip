@@ -23,6 +23,11 @@
 //     stream, one ds_read_b128 + one buffer store per second fragment (see DEFERRED ROW SWEEP below).  Measured A/B on one box
 //     (LG_U3_NO_DEFER=1 variant): convT3 forward 113.4 -> 111.3 us, conv2 data gradient 124 -> 120.5 us, convT4 forward within noise
 //     (172-178 both ways): the row phase was the small part of the non-MFMA share (staging + the two barriers stay).
+//   * (round 4, measured and removed) convT4 forward WITHOUT the staging area: double-buffered halo, one barrier per step, every wave
+//     storing its accumulators as 8-byte buffer stores (two lanes = 16 contiguous bytes of a pixel's 64-byte row): correct, and 192 us
+//     against 137 — sixteen scattered 16-byte-segment stores per wave and step are what the staging area exists to avoid.  Also
+//     without effect on that layer: the halo requested / committed by the three waves that leave their class loop early (153.5 vs
+//     153.6 us), a start delay of the second workgroup of a CU (141.6 / 143.2 / 143.0 / 145.1 us for 0 / 5 / 9 / 13 k cycles).
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
@@ -154,7 +159,10 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
 #pragma unroll
     for (int t = 0; t < C::NT; ++t) ok[t] = tile_of(step, t, n[t], y0[t], x0[t]);
     // the NT tiles of a step are consecutive items: the second one lies in the same sample or in the next
-    const int nrec = (p.B - n[0] >= 2 ? 2 : 1) * sample_elems * 2;
+    // (readfirstlane: hipcc forms this select on the VALU, can then no longer prove the descriptor wave-uniform and wraps EVERY halo
+    //  load in a waterfall loop — four v_readfirstlane, two compares, exec juggling, one load at a time; found in the .s in round 4,
+    //  it had been there since round 2: 54 -> 8 v_readfirstlane per kernel.  cdna_hip_programming.md T20.)
+    const int nrec = __builtin_amdgcn_readfirstlane((p.B - n[0] >= 2 ? 2 : 1) * sample_elems * 2);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.src + (long long)n[0] * sample_elems), 0, nrec, 0x00027000);
 #pragma unroll
     for (int u = 0; u < C::PPT; ++u) {
@@ -414,8 +422,9 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
       __syncthreads();  // tile staged, next halo in place; its rows leave inside the next class loop (or below, after the last step)
 #pragma unroll
       for (int t = 0; t < C::NT; ++t) {
-        pbyte[t] = (unsigned)((((long long)(tns[t] * 2 * p.Hs + 2 * ty0s[t]) * (2 * p.Ws) + 2 * tx0s[t]) * N) * 2);
-        pnrec[t] = tlive[t] ? out_bytes : 0u;
+        // (readfirstlane: both ride in scalar operands of the row stores — descriptor size and scalar offset; see issue())
+        pbyte[t] = (unsigned)__builtin_amdgcn_readfirstlane((int)((((long long)(tns[t] * 2 * p.Hs + 2 * ty0s[t]) * (2 * p.Ws) + 2 * tx0s[t]) * N) * 2));
+        pnrec[t] = (unsigned)__builtin_amdgcn_readfirstlane((int)(tlive[t] ? out_bytes : 0u));
       }
     } else
     // ---- whole output rows out: 16 rows x (32 pixels x N channels) contiguous, 16 B per lane ------------------------------
