@@ -60,6 +60,9 @@ constexpr int DBG = LG_D3_DBG;
 #ifndef LG_D3_SCHED
 #define LG_D3_SCHED 1   // 0: tap body in three pinned groups (A reads | MFMAs | ring refill); 1: interleaved by sched_group_barrier
 #endif
+#ifndef LG_D3_HALO_AUX
+#define LG_D3_HALO_AUX 0   // cache policy bits of the halo loads (2 = nt: streamed-once activations; A/B builds)
+#endif
 #ifndef LG_D3_ADEPTH
 #define LG_D3_ADEPTH 2  // A-fragment buffers: 2 = requested one tap ahead, 3 = two taps ahead
 #endif
@@ -236,14 +239,14 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16*>(p.src + (long long)it.n * sample_elems), 0, (PAIR ? 2 : 1) * sample_elems * 2, 0x00027000);
 #pragma unroll
-    for (int u = 0; u < PPT; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hoff[u] + (unsigned)(c0 * 2), 0, 0));
+    for (int u = 0; u < PPT; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hoff[u] + (unsigned)(c0 * 2), 0, LG_D3_HALO_AUX));
   };
   auto issue_g = [&](const Item& it, int c0, u32x4 (&v)[NORM == 2 ? PPT : 1]) __attribute__((always_inline)) {   // BWDNORM: the same pieces of g
     if constexpr (NORM == 2) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<__bf16*>(p.gsrc + (long long)it.n * sample_elems), 0, sample_elems * 2, 0x00027000);
 #pragma unroll
-      for (int u = 0; u < PPT; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hoff[u] + (unsigned)(c0 * 2), 0, 0));
+      for (int u = 0; u < PPT; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hoff[u] + (unsigned)(c0 * 2), 0, LG_D3_HALO_AUX));
     }
   };
   u32x4 gv[NORM == 2 ? PPT : 1];

@@ -49,10 +49,11 @@ def parse(name):
 def short(name):
     base, a = parse(name)
     t = lambda i, d=None: a[i] if i < len(a) else d
-    if base == "conv_down3_kernel":      # <STATS, FUSE, PAIR = false, NW = 128, NORM = false>
+    if base == "conv_down3_kernel":      # <STATS, FUSE, PAIR = false, NW = 128, NORM = 0>; NORM: 0 none, 1 forward norm, 2 BWDNORM (round 3: a bool)
         if t(2) == "true":
             return "conv_down3_kernel<PAIR>"
-        return f"conv_down3_kernel<NW={t(3, '128')}" + (",NORM>" if t(4) == "true" else ">")
+        norm = {"true": ",NORM", "1": ",NORM", "2": ",BWDNORM"}.get(t(4, "0"), "")
+        return f"conv_down3_kernel<NW={t(3, '128')}{norm}>"
     if base == "conv_up3_kernel":        # <CS, N, STATS, FUSE, NTT = tiles per step>; (64, 32) with one tile per step = the 4-wave form
         return f"conv_up3_kernel<{t(0)},{t(1)}" + (",4w>" if (t(1) == "32" and t(4, "2") == "1") else ">")
     if base == "conv_halo_kernel":       # <T, MODE, KCH, DBUF, SRC16, RES, ...>

@@ -16,6 +16,11 @@ CASES = [
     ("conv_down3_kernel<true, false, true, 128>", "conv_down3_kernel<PAIR>"),
     ("conv_down3_kernel<true, false, false, 128, true>", "conv_down3_kernel<NW=128,NORM>"),
     ("conv_down3_kernel<true, false, false, 128, false>", "conv_down3_kernel<NW=128>"),
+    ("conv_down3_kernel<true, false, false, 128, 1>", "conv_down3_kernel<NW=128,NORM>"),
+    ("conv_down3_kernel<false, true, false, 64, 2>", "conv_down3_kernel<NW=64,BWDNORM>"),
+    ("conv_down3_kernel<false, true, false, 64, 0>", "conv_down3_kernel<NW=64>"),
+    ("_ZN12_GLOBAL__N_117conv_down3_kernelILb0ELb1ELb0ELi64ELi2EEEvNS_8D3ParamsE", "conv_down3_kernel<NW=64,BWDNORM>"),
+    ("_ZN12_GLOBAL__N_117conv_down3_kernelILb1ELb0ELb0ELi128ELi1EEEvNS_8D3ParamsE", "conv_down3_kernel<NW=128,NORM>"),
     ("_ZN12_GLOBAL__N_119s1t_fwd_rows_kernelILi32ELb1ELi2EEEvPKDF16bPKfS4_PfiiiiNS_10RowsNormInE", "s1t_fwd_rows_kernel<32,NORM>"),
     ("n3_wgrad16_kernel<1, 16>", "n3_wgrad16_kernel<1,16>"),
     ("conv_up3_kernel<128, 64, false, true>", "conv_up3_kernel<128,64>"),
