@@ -707,3 +707,52 @@ def test_odd_batch_on_the_8x8_level_takes_another_kernel(ops, layer):
     assert _rms(_f64(z), _f64(torch.cat([z4, z1], 0))) < 6e-4          # (flipped bf16 roundings only)
     sa, sb = _f64(ops.stats_tensor(st)), _f64(torch.cat([ops.stats_tensor(st4), ops.stats_tensor(st1)], 0))
     assert np.abs(sa[:, :5] - sb[:, :5]).max() < 1e-4 * (np.abs(sa[:, :5]).max() + 1.0)
+
+
+@pytest.mark.parametrize("B", [256, 512])
+@pytest.mark.parametrize("layer", [l for l in LAYERS if l[2] != 3], ids=[l[0] for l in LAYERS if l[2] != 3])
+def test_persistent_kernels_are_deterministic(ops, layer, B):
+    """Round 4 met a build of one persistent kernel (the BWDNORM form of conv_down3 with its per-item record read by vector loads) whose
+    output changed from launch to launch with two blocks per CU while every single result was within rounding of the oracle — only a
+    bit-for-bit comparison shows that.  Here: forward with fused moments, fused data gradient and weight gradient of every stride-2 layer
+    at the launch sizes, three launches each on the same inputs (cache-warm, back to back), bit for bit."""
+    name, kind, cb, cs, s = layer
+    w = _rand((5, 5, cb, cs), 81, 0.05)
+    pack = ops.conv_pack(w, cb, cs, 1)
+    gm, bt = torch.tensor([1.1], device="cuda"), torch.tensor([0.05], device="cuda")
+    big16 = _rand((B, 2 * s, 2 * s, cb), 82).to(torch.bfloat16)
+    small16 = _rand((B, s, s, cs), 83).to(torch.bfloat16)
+    bias = _rand((cs if kind == "conv" else cb,), 84, 0.1)
+
+    def fwd():
+        if kind == "conv":
+            z, st = ops.conv2d_s2_fwd_stats(None, pack, bias, cs, 1, gm, bt, x16=big16, z16=True)
+        else:
+            z, st = ops.convT_s2_fwd_stats(None, pack, bias, cb, 1, gm, bt, x16=small16, z16=True)
+        return z, ops.stats_tensor(st)
+
+    zl16 = big16 if kind == "conv" else small16            # stands for the raw output of the level the gradient belongs to
+    stl = ops.instnorm_stats(zl16.float(), gm, bt, 0, ALPHA)
+
+    def dgrad():
+        if kind == "conv":
+            g, p = ops.conv2d_s2_dgrad(None, pack, cb, 1, dy16=small16, out_bf16=True, fuse=(zl16, stl, ALPHA))
+        else:
+            g, p = ops.convT_s2_dgrad(None, pack, cs, 1, dy16=big16, out_bf16=True, fuse=(zl16, stl, ALPHA))
+        return g, (p.buf[:B * p.nparts * 16].clone() if p is not None else torch.zeros(1, device="cuda"))
+
+    def wgrad():
+        dw = torch.empty(5, 5, cb, cs, device="cuda")
+        if kind == "conv":
+            ops.conv2d_s2_wgrad(None, None, dw, False, 1, x16=big16, dy16=small16)
+        else:
+            ops.convT_s2_wgrad(None, None, dw, False, 1, x16=small16, dy16=big16)
+        return (dw,)
+
+    for fn in (fwd, dgrad, wgrad):
+        first = [t.clone() for t in fn()]
+        for rep in range(2):
+            again = fn()
+            torch.cuda.synchronize()
+            for a, b in zip(first, again):
+                assert torch.equal(a, b), (name, fn.__name__, rep)
