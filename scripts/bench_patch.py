@@ -41,3 +41,7 @@ print(f"conv1 wgrad                 {timeit(lambda: ops.conv2d_s2_wgrad(img, Non
 h16 = torch.randn(B, 128, 128, 32, device="cuda").to(torch.bfloat16)
 dwf, dbf = torch.empty(5, 5, 3, 32, device="cuda"), torch.empty(3, device="cuda")
 print(f"final wgrad                 {timeit(lambda: ops.convT_s1_tanh_bwd(None, dpre, pf, 32, 1, dw=dwf, db=dbf, x16=h16)):8.1f} us", flush=True)
+bf = torch.zeros(3, device="cuda")
+yo = torch.empty(B, 128, 128, 3, device="cuda")
+print(f"final fwd (h16 in)          {timeit(lambda: ops.convT_s1_tanh_fwd(None, pf, bf, 3, 1, out=yo, x16=h16)):8.1f} us", flush=True)
+print(f"final fwd (raw z16 + norm)  {timeit(lambda: ops.convT_s1_tanh_fwd_z16(z16, st, 0.3, pf, bf, 3, 1, out=yo)):8.1f} us", flush=True)
