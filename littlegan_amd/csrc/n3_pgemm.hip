@@ -13,6 +13,7 @@
 // Weights come from the verbatim fp32 copy in the pack (pack.hip, cb == 3) and are rounded to bf16 (RNE) here, the
 // same rounding the packed MFMA operands get; accumulation is fp32 throughout.
 #include <stdlib.h>
+#include <type_traits>
 #include "lg_common.h"
 
 namespace {
@@ -180,46 +181,58 @@ __global__ __launch_bounds__(256) void up_p16_kernel(const __bf16* __restrict__ 
 // "patch" layers: the 3-channel tensor is the SOURCE (K = 5*5*3 = 75, N = 32 or 64 wide).
 //   S = 2, pad 1 : Encoder.conv1 forward        z[B,H,W,N]   = conv2d_s2(img[B,2H,2W,3]) + b        model.py:15
 //   S = 1, pad 2 : final layer's data gradient  dx[B,H,W,N]  = sum_{k,co} dpre[i+k-2][co] W[k][co][:]  model.py:86-87
-// Both are  out[o][n] = b[n] + sum_k patch(o)[k] * w[k*N + n],  k = (ky, kx, c3).  For a fixed ky the 15 values
-// (kx, c3) are 15 CONSECUTIVE floats of source row S*y+ky-pad starting at pixel S*x-pad, so K is laid out as 6 groups
-// of 16 (15 real + 1 zero-weight slot; group 5 all zero-weight): a 16x16x32 A fragment is 8 consecutive floats of an
-// LDS image tile per lane, no index table.  These layers are bound by their OUTPUT stream (N floats per pixel), so
+// Both are  out[o][n] = b[n] + sum_k patch(o)[k] * w[k*N + n],  k = (ky, kx, c3).  The image tile lives in LDS as bf16 RGBx
+// pixels (8 bytes: three channels + a zero) and K is laid out as (ky, kx, c4) with SIX pixels per filter row (kx = 5 and c4 = 3
+// carry zero weights): 5 x 24 = 120 -> 128 = four k-steps of 32.  The 8 elements of a lane's A fragment are then TWO NEIGHBOURING
+// PIXELS of one tile row — one ds_read_b128 (S = 2: always 16-B aligned) or one ds_read2_b64 (S = 1) per k-step, no conversion.
+// (Round 4.  Before: fp32 pixels of 12 bytes, K = 6 groups of 16 consecutive floats, 96 = three k-steps — a fragment was 8 scalar
+//  LDS reads + 5 conversions + 4 byte shuffles, 39 of the ~95 instructions of a 16-pixel row segment in a kernel whose four waves
+//  per SIMD fill 96 % of the issue slots; 8 MFMAs instead of 6 per segment are the price.)
+// These layers are bound by their OUTPUT stream (N floats per pixel), so
 // the C tiles go through LDS and leave as 16-B-per-lane stores of whole contiguous rows; the conv1 form also emits
 // the per-block InstanceNorm moments {count, mean, M2} (same record as conv_halo.hip) so no pass re-reads z.
 // --------------------------------------------------------------------------------------------------------------
 template <int S, int N, bool OUT16, bool STATS, bool FUSE = false>
-__global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict__ src, const float* __restrict__ w,
+__global__ __launch_bounds__(256, N == 64 ? 3 : 4) void patch_p16_kernel(const float* __restrict__ src, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         __bf16* __restrict__ out16, double* __restrict__ spart, int B,
                                                         int H, int W, int pad, LgNormFuse nf = LgNormFuse{}) {
   static_assert(!FUSE || (OUT16 && !STATS), "norm-backward sums: bf16 data-gradient form only");
-  constexpr int NT = N / 16, HSIDE = S * (TS - 1) + 5, ROWF = HSIDE * 3, TROWS = HSIDE + 2;
+  constexpr int NT = N / 16, HSIDE = S * (TS - 1) + 5, PW = (HSIDE + 2) & ~1, TROWS = HSIDE + 1, NKS = 4;
   constexpr int MTW = TS / 4;  // m-tiles (tile rows of 16 pixels) per wave
-  __shared__ __attribute__((aligned(16))) float tile[TROWS * ROWF + 4];
+  // TROWS x PW pixels of 8 bytes; row HSIDE and the pixels right of column HSIDE - 1 stay zero (touched by zero-weight slots only)
+  __shared__ __attribute__((aligned(16))) bf16x4 tile[TROWS * PW];
   __shared__ __attribute__((aligned(16))) float cst[4][16 * N];
   __shared__ double sred[40];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const int tpx = W / TS, tpi = tpx * (H / TS), ntiles = B * tpi;
   const int Hs = S * H, Ws = S * W;
 
-  // B fragments (constant for the block): lane (n = l&15, g) holds k' = 32 ks + 8 g + j, group ky = k'/16, slot kk = k'%16
-  bf16x8 bf[3][NT];
+  // B fragments (constant for the block): lane (n = l&15, g) holds k' = 32 ks + 8 g + j = 24 ky + 4 kx + c4
+  bf16x8 bf[NKS][NT];
 #pragma unroll
-  for (int ks = 0; ks < 3; ++ks)
+  for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       bf16x8 v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int kp = 32 * ks + 8 * g + j, ky = kp >> 4, kk = kp & 15;
-        v[j] = (ky < 5 && kk < 15) ? (__bf16)w[(long long)(ky * 15 + kk) * N + nt * 16 + r] : (__bf16)0.f;
+        const int kp = 32 * ks + 8 * g + j, ky = kp / 24, rem = kp - 24 * ky, kx = rem >> 2, c4 = rem & 3;
+        v[j] = (ky < 5 && kx < 5 && c4 < 3) ? (__bf16)w[(long long)(ky * 15 + kx * 3 + c4) * N + nt * 16 + r] : (__bf16)0.f;
       }
       bf[ks][nt] = v;
     }
+  // A fragment of k-step ks: pixels (S r + 2 kxp, + 1) of tile row S ly + ky, (ky, kxp) = (k' / 24, (k' % 24) / 8), k' = 32 ks + 8 g
+  int aoff[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int kp = 32 * ks + 8 * g, ky = kp / 24, kxp = (kp - 24 * ky) >> 3;
+    aoff[ks] = ky * PW + S * r + 2 * kxp;
+  }
   float bv[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bv[nt] = bias ? bias[nt * 16 + r] : 0.f;
-  for (int i = HSIDE * ROWF + threadIdx.x; i < TROWS * ROWF + 4; i += 256) tile[i] = 0.f;  // rows the zero-weight slots touch
+  for (int i = threadIdx.x; i < TROWS * PW; i += 256) tile[i] = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
 
   // the halo of the NEXT tile is requested (global -> registers) before this tile's MFMAs and written to LDS behind them:
   // the block no longer sits out a global-memory latency per tile (measured: 66-71 % of the wave cycles were parked)
@@ -244,8 +257,8 @@ __global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict_
     for (int u = 0; u < NPT; ++u) {
       const int i = threadIdx.x + u * 256;
       if (i < HSIDE * HSIDE) {
-        float* d = tile + i * 3;
-        d[0] = hv[u][0]; d[1] = hv[u][1]; d[2] = hv[u][2];
+        const int hy = i / HSIDE, hx = i - hy * HSIDE;
+        tile[hy * PW + hx] = bf16x4{(__bf16)hv[u][0], (__bf16)hv[u][1], (__bf16)hv[u][2], (__bf16)0.f};   // RNE, as the fragment build did
       }
     }
   };
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict_
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int n = t / tpi, tt = t - n * tpi;
     const int y0 = (tt / tpx) * TS, x0 = (tt % tpx) * TS;
-    __syncthreads();  // previous tile fully consumed
+    __syncthreads();  // previous tile fully consumed (first tile: the zero fill is complete)
     halo_store();
     __syncthreads();
     if (t + (int)gridDim.x < ntiles) halo_load(t + gridDim.x);
@@ -265,22 +278,38 @@ __global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict_
     float s1 = 0.f, s2 = 0.f;  // sum and sum of squares about `shift` (the first bias: close enough to the block mean)
     const float shift = STATS ? (bias ? bias[0] : 0.f) : 0.f;
     float* cw = cst[wid];
-#pragma unroll 1
-    for (int i = 0; i < MTW; ++i) {
+    // FUSE: the z pieces of the wave's MTW tile rows are requested HERE, before the matrix work — read where they are used, each
+    // was a load waited for at once (one 1-KB request in flight per wave, 16 KB per CU, and the form cost 60 us over the plain one)
+    constexpr int NQZ = FUSE ? 16 * N / 8 / 64 : 1;
+    u32x4 zpre[FUSE ? MTW * NQZ : 1];
+    (void)zpre;
+    if constexpr (FUSE) {
+#pragma unroll
+      for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int q = 0; q < NQZ; ++q)
+          zpre[i * NQZ + q] = *reinterpret_cast<const u32x4*>(nf.z + ((long long)(n * H + y0 + wid * MTW + i) * W + x0) * N + (q * 64 + lane) * 8);
+    }
+    auto mtile = [&](auto i_c) {
+      const int i = i_c;   // FUSE: a compile-time constant (the prefetched pieces are registers, not a runtime-indexed array)
       const int ly = wid * MTW + i;
       f32x4 acc[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x8 a[NKS];
 #pragma unroll
-      for (int ks = 0; ks < 3; ++ks) {
-        const int ky = 2 * ks + (g >> 1), kk = 8 * (g & 1);
-        const float* ap = tile + (S * ly + ky) * ROWF + S * r * 3 + kk;
-        bf16x8 a;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = (__bf16)ap[j];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[ks][nt], acc[nt], 0, 0, 0);
+      for (int ks = 0; ks < NKS; ++ks) {
+        const bf16x4* ap = tile + S * ly * PW + aoff[ks];
+        if constexpr (S == 2) a[ks] = *reinterpret_cast<const bf16x8*>(ap);   // pixel index even: 16-B aligned
+        else {
+          const bf16x4 lo = ap[0], hi = ap[1];
+          a[ks] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
       }
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], bf[ks][nt], acc[nt], 0, 0, 0);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -301,9 +330,8 @@ __global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict_
           v[4] = (__bf16)b[0]; v[5] = (__bf16)b[1]; v[6] = (__bf16)b[2]; v[7] = (__bf16)b[3];
           *reinterpret_cast<bf16x8*>(out16 + o0 + idx * 8) = v;
           if constexpr (FUSE) {
-            const u32x4 zq = *reinterpret_cast<const u32x4*>(nf.z + o0 + idx * 8);
             const lg_const_f32p sp = lg_as_const(nf.stats + (long long)n * 8);   // scalar loads (lg_common.h)
-            lg_nf_accum(__builtin_bit_cast(u32x4, v), zq, sp[0], sp[4], sp[2], sp[3], nf.alpha, nf1, nf2);
+            lg_nf_accum(__builtin_bit_cast(u32x4, v), zpre[i * NQZ + q], sp[0], sp[4], sp[2], sp[3], nf.alpha, nf1, nf2);
           }
         }
       } else {
@@ -314,6 +342,14 @@ __global__ __launch_bounds__(256) void patch_p16_kernel(const float* __restrict_
         }
       }
       __builtin_amdgcn_wave_barrier();
+    };
+    if constexpr (FUSE) {   // unrolled: the prefetched pieces are registers, not a runtime-indexed array
+      mtile(std::integral_constant<int, 0>{}); mtile(std::integral_constant<int, 1>{});
+      mtile(std::integral_constant<int, 2>{}); mtile(std::integral_constant<int, 3>{});
+      static_assert(MTW == 4, "four tile rows per wave");
+    } else {
+#pragma unroll 1
+      for (int i = 0; i < MTW; ++i) mtile(i);   // a runtime row index: one copy of the body
     }
 
     if constexpr (FUSE) {  // one record per (sample, tile): S1 = sum g', S2 = sum g' c
