@@ -200,11 +200,12 @@ __global__ __launch_bounds__(256, N == 64 ? 3 : 4) void patch_p16_kernel(const f
   static_assert(!FUSE || (OUT16 && !STATS), "norm-backward sums: bf16 data-gradient form only");
   constexpr int NT = N / 16, HSIDE = S * (TS - 1) + 5, PW = (HSIDE + 2) & ~1, TROWS = HSIDE + 1, NKS = 4;
   constexpr int MTW = TS / 4;  // m-tiles (tile rows of 16 pixels) per wave
+  constexpr bool HAS_BIAS = S == 2;   // the stride-1 form is the final layer's data gradient: no bias term
   // TROWS x PW pixels of 8 bytes; row HSIDE and the pixels right of column HSIDE - 1 stay zero (touched by zero-weight slots only)
   __shared__ __attribute__((aligned(16))) bf16x4 tile[TROWS * PW];
   __shared__ __attribute__((aligned(16))) float cst[4][16 * N];
   __shared__ double sred[40];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, g = lane >> 4;
   const int tpx = W / TS, tpi = tpx * (H / TS), ntiles = B * tpi;
   const int Hs = S * H, Ws = S * W;
 
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256, N == 64 ? 3 : 4) void patch_p16_kernel(const f
     // contiguous rows out, 16 B per lane.  No block barrier in here: LDS operations of one wave execute in order.
     float nf1 = 0.f, nf2 = 0.f;  // FUSE: norm-backward sums of the gradient this tile writes (lg_common.h)
     (void)nf1; (void)nf2;
-    float s1 = 0.f, s2 = 0.f;  // sum and sum of squares about `shift` (the first bias: close enough to the block mean)
+    f32x2 s1v = {0.f, 0.f}, s2v = {0.f, 0.f};  // sum and sum of squares about `shift` (the first bias: close enough to the block mean)
     const float shift = STATS ? (bias ? bias[0] : 0.f) : 0.f;
     float* cw = cst[wid];
     // FUSE: the z pieces of the wave's MTW tile rows are requested HERE, before the matrix work — read where they are used, each
@@ -313,10 +314,16 @@ __global__ __launch_bounds__(256, N == 64 ? 3 : 4) void patch_p16_kernel(const f
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = acc[nt][e] + bv[nt];
-          if constexpr (STATS) { const float d = v - shift; s1 += d; s2 += d * d; }
-          cw[(4 * g + e) * N + nt * 16 + r] = v;  // C layout: col = lane&15, row = 4(lane>>4)+e
+        for (int e2 = 0; e2 < 2; ++e2) {   // two accumulator rows at a time: v_pk_add_f32 / v_pk_fma_f32 halve the VALU count
+          f32x2 v = {acc[nt][2 * e2], acc[nt][2 * e2 + 1]};
+          if constexpr (HAS_BIAS) v += f32x2{bv[nt], bv[nt]};
+          if constexpr (STATS) {
+            const f32x2 d = v - f32x2{shift, shift};
+            s1v += d;
+            s2v = __builtin_elementwise_fma(d, d, s2v);
+          }
+          cw[(4 * g + 2 * e2) * N + nt * 16 + r] = v[0];  // C layout: col = lane&15, row = 4(lane>>4)+e
+          cw[(4 * g + 2 * e2 + 1) * N + nt * 16 + r] = v[1];
         }
       __builtin_amdgcn_wave_barrier();
       const long long o0 = ((long long)(n * H + y0 + ly) * W + x0) * N;  // 16 pixels x N contiguous
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(256, N == 64 ? 3 : 4) void patch_p16_kernel(const f
     }
     if constexpr (STATS) {  // moments of this block's 256 x N outputs (one sample per block): {count, mean, M2}
       const double cnt = 256.0 * N;
-      double red[2] = {(double)s1, (double)s2};
+      double red[2] = {(double)s1v[0] + (double)s1v[1], (double)s2v[0] + (double)s2v[1]};
       lg_block_sum_d<2>(red, sred);
       if (threadIdx.x == 0) {
         double* o = spart + ((long long)n * tpi + tt) * 3;
