@@ -230,8 +230,18 @@ __global__ __launch_bounds__(256) void n3_wgrad_kernel(const float* __restrict__
 // consecutive x') at a compile-time-free address — it was 8 scalar LDS reads + 8 conversions per fragment, 24 per k step and lane,
 // out of a fp32 halo.  The planes are filled by scattering every halo value, rounded once, to the <= 5 (S = 1) | 3 (S = 2) planes it
 // appears in (2-byte stores, an invalid target goes to a per-thread dump slot: no branch).  Rows of (tap, c3) >= 75 read a zero region.
+#ifndef LG_N3W_DBG
+#define LG_N3W_DBG 0   // compile-time ablation bits (timing only, results wrong): 1 no plane scatter, 2 no 3-channel loads, 4 no wide-operand loads, 8 no MFMA, 16 no wide-operand LDS stores
+#endif
+// 64 channels (NT = 2): the waves split the CHANNELS as well as the pixels — wave w owns channel half w & 1 and tile rows 4 (w >> 1) ..
+// + 3 — so a wave carries 48 accumulator registers instead of 96 and the kernel fits FOUR blocks per CU (it took 256 registers and two
+// blocks: every ablation of round 4 that happened to free registers ran the conv1 weight gradient in ~100 instead of 164 us whatever it
+// removed; held to 168 registers by launch bounds alone it spilled 73).
+#ifndef LG_N3W_LB
+#define LG_N3W_LB 3   // blocks per CU the 64-channel forms are compiled for (A/B builds)
+#endif
 template <int NT, int TH = 8, int S = 1>
-__global__ __launch_bounds__(256) void n3_wgrad16_kernel(const float* __restrict__ big3, const __bf16* __restrict__ small16,
+__global__ __launch_bounds__(256, NT == 2 ? LG_N3W_LB : 1) void n3_wgrad16_kernel(const float* __restrict__ big3, const __bf16* __restrict__ small16,
                                                          float* __restrict__ slab, int B, int H, int W, int s_unused, int pad) {
   static_assert(TH == 8 || (TH == 16 && NT == 1 && S == 1), "tile heights");   // (64 channels, stride 2 on 16-row tiles: 328 VGPRs, or 61 spills at two blocks per CU: 164 -> 248 us)
   static_assert(S == 1 || S == 2, "strides");
@@ -257,11 +267,16 @@ __global__ __launch_bounds__(256) void n3_wgrad16_kernel(const float* __restrict
     aoff[i] = (idx < 75 ? ((c3 * 5 + t % 5) * HH + t / 5) * 32 : PL_ZERO) + h * 16;
   }
   for (int i = threadIdx.x; i < (s * TH + 1) * 8; i += 256) reinterpret_cast<unsigned*>(sP + PL_ZERO)[i] = 0u;   // (the first barrier of the tile loop publishes it)
-  f32x16 acc[3][NT];
+  constexpr bool CSPLIT = NT == 2;
+  constexpr int NTW = CSPLIT ? 1 : NT;            // 32-channel column tiles per wave
+  constexpr int KSW = CSPLIT ? TH / 2 : TH / 4;   // k steps (tile rows of 16 pixels) per wave
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const int chw = CSPLIT ? (wu & 1) : 0, kw = CSPLIT ? (wu >> 1) : wu;
+  f32x16 acc[3][NTW];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   // ds_read_b64_tr_b16 addressing (as wgrad_igemm.hip): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3
@@ -283,14 +298,17 @@ __global__ __launch_bounds__(256) void n3_wgrad16_kernel(const float* __restrict
     for (int u = 0; u < NPB; ++u) {
       const int i = threadIdx.x + u * 256, pix = i / (Cs / 8), c8 = i % (Cs / 8);
       const int yy = y0 + pix / TW, xx = x0 + pix % TW;
-      rb[u] = *reinterpret_cast<const u32x4*>(small16 + ((long long)(n * H + yy) * W + xx) * Cs + c8 * 8);
+      if constexpr (!(LG_N3W_DBG & 4)) rb[u] = *reinterpret_cast<const u32x4*>(small16 + ((long long)(n * H + yy) * W + xx) * Cs + c8 * 8);
+      else rb[u] = u32x4{(unsigned)yy, (unsigned)xx, 0u, 0u};
     }
 #pragma unroll
     for (int u = 0; u < NPA; ++u) {
       const int i = threadIdx.x + u * 256, hp = i / 3, c3 = i - hp * 3;
       const int sy = s * y0 - pad + hp / HW, sx = s * x0 - pad + hp % HW;
       float v = 0.f;
-      if (i < HH * HW * 3 && (unsigned)sy < (unsigned)Hb && (unsigned)sx < (unsigned)Wb) v = big3[((long long)(n * Hb + sy) * Wb + sx) * 3 + c3];
+      if constexpr (!(LG_N3W_DBG & 2)) {
+        if (i < HH * HW * 3 && (unsigned)sy < (unsigned)Hb && (unsigned)sx < (unsigned)Wb) v = big3[((long long)(n * Hb + sy) * Wb + sx) * 3 + c3];
+      } else v = (float)(sy + sx);
       ra[u] = v;
     }
   };
@@ -298,10 +316,11 @@ __global__ __launch_bounds__(256) void n3_wgrad16_kernel(const float* __restrict
 #pragma unroll
     for (int u = 0; u < NPB; ++u) {
       const int i = threadIdx.x + u * 256, pix = i / (Cs / 8), c8 = i % (Cs / 8);
-      *reinterpret_cast<u32x4*>(sB + pix * RSB + c8 * 16) = rb[u];
+      if constexpr (!(LG_N3W_DBG & 16)) *reinterpret_cast<u32x4*>(sB + pix * RSB + c8 * 16) = rb[u];
+      else if (rb[u][0] == 0x12345u) *reinterpret_cast<u32x4*>(sB + pix * RSB + c8 * 16) = rb[u];
     }
 #pragma unroll
-    for (int u = 0; u < NPA; ++u) {
+    for (int u = 0; u < ((LG_N3W_DBG & 1) ? 0 : NPA); ++u) {
       const int i = threadIdx.x + u * 256, hp = i / 3, c3 = i - hp * 3, yrow = hp / HW, xh = hp - yrow * HW;
       const __bf16 b = (__bf16)ra[u];
       const unsigned short bits = __builtin_bit_cast(unsigned short, b);
@@ -322,15 +341,15 @@ __global__ __launch_bounds__(256) void n3_wgrad16_kernel(const float* __restrict
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) tile_load(tile + gridDim.x);
 #pragma unroll
-    for (int ks = 0; ks < TH / 4; ++ks) {
-      const int ly = (TH / 4) * wid + ks;  // tile row = the 16 pixels of this k step
-      bf16x8 a[3], b[NT];
+    for (int ks = 0; ks < KSW; ++ks) {
+      const int ly = KSW * kw + ks;  // tile row = the 16 pixels of this k step
+      bf16x8 a[3], b[NTW];
 #pragma unroll
       for (int i = 0; i < 3; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sP + aoff[i] + s * ly * 32);
       const int row0 = ly * TW + 8 * (g >> 1) + lq;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const char* pb = sB + row0 * RSB + (j * 32 + colbase) * 2;
+      for (int j = 0; j < NTW; ++j) {
+        const char* pb = sB + row0 * RSB + ((chw * NTW + j) * 32 + colbase) * 2;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb + 4 * RSB));
         typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -340,22 +359,26 @@ __global__ __launch_bounds__(256) void n3_wgrad16_kernel(const float* __restrict
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NTW; ++j) {
+          if constexpr (!(LG_N3W_DBG & 8)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          else acc[i][j][0] += (float)a[i][0] * (float)b[j][0];
+        }
     }
+    if constexpr ((LG_N3W_DBG & 1) != 0) { if (ra[0] == 12345.678f) sP[threadIdx.x] = 1; }   // keeps the 3-channel loads alive
   }
-  float* mrg = reinterpret_cast<float*>(sB);  // merge the four waves in wave order (sB is dead), one slab per block
-  for (int w = 0; w < 4; ++w) {
+  float* mrg = reinterpret_cast<float*>(sB);  // merge the waves' pixel shares in order (sB is dead), one slab per block
+  for (int w = 0; w < (CSPLIT ? 2 : 4); ++w) {
     __syncthreads();
-    if (wid == w) {
+    if (kw == w) {
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             if (row < 75) {
-              float* q = mrg + row * Cs + j * 32 + r;
+              float* q = mrg + row * Cs + (chw * NTW + j) * 32 + r;
               *q = (w == 0 ? 0.f : *q) + acc[i][j][e];
             }
           }
@@ -393,11 +416,12 @@ __global__ __launch_bounds__(256) void n3_slab_reduce_kernel(const float* __rest
   }
 }
 
-// persistent blocks: measured best at 2 per CU for Cs 64 (41 KB LDS; 3 per CU was 30 % slower) and 6 per CU for Cs 32 (19 KB)
+// persistent blocks: Cs 64: 3 per CU since the channel-split waves of round 4 (168 registers; 512 / 768 / 1024 blocks: 173 / 138 / 180 us
+// at 2B; before, at 256 registers, 2 per CU was best); Cs 32: 3 per CU (512 / 768 / 1024 / 1536: 121 / 112 / 127 / 120 us with its bias sums)
 inline int wgrad_blocks(int ntiles, int Cs) {
   static int f32 = -1, f64 = -1;
   if (f32 < 0) { const char* e = getenv("LG_N3W_CAP32"); f32 = e ? atoi(e) : 0; const char* g = getenv("LG_N3W_CAP64"); f64 = g ? atoi(g) : 0; }
-  const int cap = Cs > 32 ? (f64 > 0 ? f64 : 512) : (f32 > 0 ? f32 : 768);  // measured with the prefetch (256..2048): Cs 64: 128 / 82 / 109 / 99 / 113 / 130 us, Cs 32: 320 / 212 / 182 / 214 / 189 / 200 us
+  const int cap = Cs > 32 ? (f64 > 0 ? f64 : 768) : (f32 > 0 ? f32 : 768);  // measured with the prefetch (256..2048): Cs 64: 128 / 82 / 109 / 99 / 113 / 130 us, Cs 32: 320 / 212 / 182 / 214 / 189 / 200 us
   return ntiles < cap ? ntiles : cap;
 }
 
