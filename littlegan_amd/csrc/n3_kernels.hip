@@ -418,10 +418,10 @@ __global__ __launch_bounds__(256) void n3_slab_reduce_kernel(const float* __rest
 
 // persistent blocks: Cs 64: 3 per CU since the channel-split waves of round 4 (168 registers; 512 / 768 / 1024 blocks: 173 / 138 / 180 us
 // at 2B; before, at 256 registers, 2 per CU was best); Cs 32: 3 per CU (512 / 768 / 1024 / 1536: 121 / 112 / 127 / 120 us with its bias sums)
-inline int wgrad_blocks(int ntiles, int Cs) {
+inline int wgrad_blocks(int ntiles, int Cs, bool f32_path = false) {
   static int f32 = -1, f64 = -1;
   if (f32 < 0) { const char* e = getenv("LG_N3W_CAP32"); f32 = e ? atoi(e) : 0; const char* g = getenv("LG_N3W_CAP64"); f64 = g ? atoi(g) : 0; }
-  const int cap = Cs > 32 ? (f64 > 0 ? f64 : 768) : (f32 > 0 ? f32 : 768);  // measured with the prefetch (256..2048): Cs 64: 128 / 82 / 109 / 99 / 113 / 130 us, Cs 32: 320 / 212 / 182 / 214 / 189 / 200 us
+  const int cap = Cs > 32 ? (f64 > 0 ? f64 : (f32_path ? 512 : 768)) : (f32 > 0 ? f32 : 768);   // (the fp32-source kernel at 64 channels: 41 KB of LDS, 2 per CU measured best)  // measured with the prefetch (256..2048): Cs 64: 128 / 82 / 109 / 99 / 113 / 130 us, Cs 32: 320 / 212 / 182 / 214 / 189 / 200 us
   return ntiles < cap ? ntiles : cap;
 }
 
@@ -473,7 +473,8 @@ extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void
   static int th8 = -1;
   if (th8 < 0) th8 = lg_env_flag("LG_N3W_TH8") ? 1 : 0;   // A/B switch
   const bool th16 = Cs == 32 && s == 1 && H % 16 == 0 && small16 && !lg_env_flag("LG_N3W_F32") && !th8;   // 16-row tiles (bf16 path, final layer)
-  const int ntiles = B * (H / (th16 ? 16 : 8)) * (W / 16), nblk = wgrad_blocks(ntiles, Cs);
+  const bool p16 = small16 && !lg_env_flag("LG_N3W_F32");
+  const int ntiles = B * (H / (th16 ? 16 : 8)) * (W / 16), nblk = wgrad_blocks(ntiles, Cs, !p16);   // (the workspace is sized for the larger grid)
   const size_t lds = (size_t)(128 * Cs + (s * 8 + 4) * (s * 16 + 4) * 3 + 4) * 4;
   const __bf16* s16 = (const __bf16*)small16;
   static bool a = false;
