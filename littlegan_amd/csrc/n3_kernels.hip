@@ -219,23 +219,24 @@ __global__ __launch_bounds__(256) void n3_wgrad_kernel(const float* __restrict__
 }
 
 // bf16 path of the same contraction: small = bf16 mirror, staged verbatim as [pixel][channel] bf16 and read as MFMA B
-// operands with ds_read_b64_tr_b16 (k = pixel is the row index); the 3-channel operand is gathered from the fp32 halo
-// as 8 consecutive pixels per lane and rounded to bf16 (RNE) — v_mfma_f32_32x32x16_bf16, 16 pixels per instruction
-// instead of 2, fp32 accumulate.  A k step = one tile row of 16 pixels; wave w owns tile rows 2w and 2w+1.
-// TH (8 | 16) = rows of a tile.  The kernel is bound by the bytes it keeps in flight (one tile ahead in registers, 3 | 2 blocks per CU at
-// 160 | 256 VGPRs: 33 | 49 KB per CU against the ~62 KB that 8 TB/s x 2 us ask for): TH = 16 doubles the tile of the 32-channel stride-1
-// layer (the final layer's weight gradient) at the same block count — 8 more VGPRs of staging registers.
-// The 3-channel operand lives in LDS as kx-SHIFTED bf16 PLANES (round 3, DESIGN 8b lever 2): plane (c3, kx) row y holds the 16 values
-// halo[y][S x' + kx][c3], x' = 0..15, so the A fragment of row (tap, c3) for the 16 pixels of a k step is ONE ds_read_b128 (8
-// consecutive x') at a compile-time-free address — it was 8 scalar LDS reads + 8 conversions per fragment, 24 per k step and lane,
-// out of a fp32 halo.  The planes are filled by scattering every halo value, rounded once, to the <= 5 (S = 1) | 3 (S = 2) planes it
-// appears in (2-byte stores, an invalid target goes to a per-thread dump slot: no branch).  Rows of (tap, c3) >= 75 read a zero region.
+// operands with ds_read_b64_tr_b16 (k = pixel is the row index) — v_mfma_f32_32x32x16_bf16, 16 pixels per instruction, fp32
+// accumulate.  A k step = one tile row of 16 pixels.
+// TH (8 | 16) = rows of a tile.  TH = 16 doubles the tile of the 32-channel stride-1 layer (the final layer's weight gradient).
+// The 3-channel operand lives in LDS as the bf16 RGBx HALO of the tile (8 bytes per pixel: three channels + a zero, rounded once,
+// RNE) and is read with the SAME transposing load (round 4): M is laid out as (ky, kx, c4) = 25 taps x 4, so the 16 columns of a
+// 16-lane group are four taps, a lane supplies the address of ITS tap's pixel for one of four consecutive k (halo pixel
+// (S ly + ky, S x' + kx): the rows of the "matrix" overlap, which the instruction does not mind), and the hardware transpose hands
+// every lane the 8 pixels of its (tap, c4) row.  100 rows -> four 32-row tiles (c4 = 3 and rows >= 100 are zero / dropped at the merge).
+// Before: 15 kx-shifted bf16 planes filled by scattering every halo value to the <= 5 planes it appears in — 15 - 27 two-byte LDS
+// stores with their selects per thread and tile, the largest item of the kernel (ablation, conv1 weight gradient at 2B: 164 -> 76 us
+// without it); now one 8-byte store per halo pixel, at the price of 4 instead of 3 row tiles of MFMAs in a kernel whose matrix pipe is
+// 6 - 10 % busy.
 #ifndef LG_N3W_DBG
-#define LG_N3W_DBG 0   // compile-time ablation bits (timing only, results wrong): 1 no plane scatter, 2 no 3-channel loads, 4 no wide-operand loads, 8 no MFMA, 16 no wide-operand LDS stores
+#define LG_N3W_DBG 0   // compile-time ablation bits (timing only, results wrong): 1 no halo stores, 2 no 3-channel loads, 4 no wide-operand loads, 8 no MFMA, 16 no wide-operand LDS stores
 #endif
 // 64 channels (NT = 2): the waves split the CHANNELS as well as the pixels — wave w owns channel half w & 1 and tile rows 4 (w >> 1) ..
-// + 3 — so a wave carries 48 accumulator registers instead of 96 and the kernel fits FOUR blocks per CU (it took 256 registers and two
-// blocks: every ablation of round 4 that happened to free registers ran the conv1 weight gradient in ~100 instead of 164 us whatever it
+// + 3 — so a wave carries 64 accumulator registers instead of 128 and the kernel fits three blocks per CU (round 4: at 256 registers
+// and two blocks every ablation that happened to free registers ran the conv1 weight gradient in ~100 instead of 164 us whatever it
 // removed; held to 168 registers by launch bounds alone it spilled 73).
 #ifndef LG_N3W_LB
 #define LG_N3W_LB 3   // blocks per CU the 64-channel forms are compiled for (A/B builds)
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void n3_wgrad_kernel(const float* __restrict__
 template <int NT, int TH = 8, int S = 1>
 __global__ __launch_bounds__(256, NT == 2 ? LG_N3W_LB : 1) void n3_wgrad16_kernel(const float* __restrict__ big3, const __bf16* __restrict__ small16,
                                                          float* __restrict__ slab, int B, int H, int W, int s_unused, int pad) {
-  static_assert(TH == 8 || (TH == 16 && NT == 1 && S == 1), "tile heights");   // (64 channels, stride 2 on 16-row tiles: 328 VGPRs, or 61 spills at two blocks per CU: 164 -> 248 us)
+  static_assert(TH == 8 || (TH == 16 && NT == 1 && S == 1), "tile heights");
   static_assert(S == 1 || S == 2, "strides");
   constexpr int s = S;
   constexpr int Cs = NT * 32, TW = 16;
@@ -251,46 +252,45 @@ __global__ __launch_bounds__(256, NT == 2 ? LG_N3W_LB : 1) void n3_wgrad16_kerne
   constexpr int SB_BYTES = (TH * TW * RSB > 75 * Cs * 4) ? TH * TW * RSB : 75 * Cs * 4;  // also the merge buffer
   extern __shared__ __attribute__((aligned(16))) char smem16[];
   constexpr int HH = s * TH + 4, HW = s * TW + 4;
-  constexpr int PL_ZERO = 15 * HH * 32;                  // after the 15 planes: 16 + 1 zero rows (a k step adds up to s (TH - 1) rows)
-  constexpr int PL_DUMP = PL_ZERO + (s * TH + 1) * 32;   // then 256 x 2 B of dump slots
+  constexpr int H_BYTES = HH * HW * 8;                   // the RGBx halo
+  constexpr int ZOFF = H_BYTES;                          // then 64 zero bytes... (a transposed read takes 8 bytes here and 8 more s*32 bytes on)
   char* sB = smem16;                                       // [TH*16][RSB] bf16
-  char* sP = smem16 + SB_BYTES;                            // planes [3][5][HH][16] bf16 | zero rows | dump slots
+  char* sH = smem16 + SB_BYTES;                            // halo [HH][HW] x 8 B | zero region
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int tpx = W / TW, tpi = tpx * (H / TH), ntiles = B * tpi;
   const int Hb = s * H, Wb = s * W;
   (void)s_unused;
-  int aoff[3];
+  // ds_read_b64_tr_b16 addressing (as wgrad_igemm.hip): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3
+  const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
+  const int colbase = 16 * (g & 1) + 4 * lp;
+  // A side: row tile i, this lane's column group = tap j = 8 i + 4 (g & 1) + lp, its rows = pixels x' = 8 (g >> 1) + lq (+ 4)
+  int aoff[4];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int idx = i * 32 + r;  // (tap, c3)
-    const int t = idx / 3, c3 = idx - t * 3;
-    aoff[i] = (idx < 75 ? ((c3 * 5 + t % 5) * HH + t / 5) * 32 : PL_ZERO) + h * 16;
+  for (int i = 0; i < 4; ++i) {
+    const int j = 8 * i + 4 * (g & 1) + lp, ky = j / 5, kx = j - 5 * ky;
+    aoff[i] = j < 25 ? (ky * HW + s * (8 * (g >> 1) + lq) + kx) * 8 : ZOFF;
   }
-  for (int i = threadIdx.x; i < (s * TH + 1) * 8; i += 256) reinterpret_cast<unsigned*>(sP + PL_ZERO)[i] = 0u;   // (the first barrier of the tile loop publishes it)
+  for (int i = threadIdx.x; i < (64 + s * 32) / 4; i += 256) reinterpret_cast<unsigned*>(sH + ZOFF)[i] = 0u;   // (the first barrier of the tile loop publishes it)
   constexpr bool CSPLIT = NT == 2;
   constexpr int NTW = CSPLIT ? 1 : NT;            // 32-channel column tiles per wave
   constexpr int KSW = CSPLIT ? TH / 2 : TH / 4;   // k steps (tile rows of 16 pixels) per wave
   const int wu = __builtin_amdgcn_readfirstlane(wid);
   const int chw = CSPLIT ? (wu & 1) : 0, kw = CSPLIT ? (wu >> 1) : wu;
-  f32x16 acc[3][NTW];
+  f32x16 acc[4][NTW];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  // ds_read_b64_tr_b16 addressing (as wgrad_igemm.hip): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3
-  const int g = lane >> 4, lq = (lane & 15) >> 2, lp = lane & 3;
-  const int colbase = 16 * (g & 1) + 4 * lp;
 
   // the NEXT tile's operands are requested (global -> registers) before this tile's MFMAs and written to LDS behind them
-  // (round 3: TWO tiles ahead in two named register sets + branch-free buffer loads for the halo — the waves are parked at
-  //  s_waitcnt / barriers 51 - 67 % of their cycles — costs 256 / 208 VGPRs and the resident blocks that hide the rest: conv1 weight
-  //  gradient 83 -> 102 us, final 177 -> 290 us at B = 256.  Dropped.)
+  // (round 3: TWO tiles ahead in two named register sets costs the resident blocks that hide the rest: conv1 weight gradient 83 -> 102 us,
+  //  final 177 -> 290 us at B = 256.  Dropped.)
   constexpr int NPB = TH * TW * (Cs / 8) / 256;          // 16-B pieces of the wide operand per thread (2 | 4)
-  constexpr int NPA = (HH * HW * 3 + 255) / 256;         // halo floats per thread: 3 (TH 8, S 1) | 5 (TH 16) | 9 (S 2)
+  constexpr int NPA = (HH * HW + 255) / 256;             // halo pixels per thread: 1 (TH 8, S 1) | 2 (TH 16) | 3 (S 2)
   u32x4 rb[NPB];
-  float ra[NPA];
+  float ra[NPA][3];
   auto tile_load = [&](int tile) {
     const int n = tile / tpi, tt = tile - n * tpi;
     const int y0 = (tt / tpx) * TH, x0 = (tt % tpx) * TW;
@@ -303,13 +303,15 @@ __global__ __launch_bounds__(256, NT == 2 ? LG_N3W_LB : 1) void n3_wgrad16_kerne
     }
 #pragma unroll
     for (int u = 0; u < NPA; ++u) {
-      const int i = threadIdx.x + u * 256, hp = i / 3, c3 = i - hp * 3;
+      const int hp = threadIdx.x + u * 256;
       const int sy = s * y0 - pad + hp / HW, sx = s * x0 - pad + hp % HW;
-      float v = 0.f;
+      ra[u][0] = 0.f; ra[u][1] = 0.f; ra[u][2] = 0.f;
       if constexpr (!(LG_N3W_DBG & 2)) {
-        if (i < HH * HW * 3 && (unsigned)sy < (unsigned)Hb && (unsigned)sx < (unsigned)Wb) v = big3[((long long)(n * Hb + sy) * Wb + sx) * 3 + c3];
-      } else v = (float)(sy + sx);
-      ra[u] = v;
+        if (hp < HH * HW && (unsigned)sy < (unsigned)Hb && (unsigned)sx < (unsigned)Wb) {
+          const float* q = big3 + ((long long)(n * Hb + sy) * Wb + sx) * 3;
+          ra[u][0] = q[0]; ra[u][1] = q[1]; ra[u][2] = q[2];
+        }
+      } else ra[u][0] = (float)(sy + sx);
     }
   };
   auto tile_store = [&]() {
@@ -321,17 +323,9 @@ __global__ __launch_bounds__(256, NT == 2 ? LG_N3W_LB : 1) void n3_wgrad16_kerne
     }
 #pragma unroll
     for (int u = 0; u < ((LG_N3W_DBG & 1) ? 0 : NPA); ++u) {
-      const int i = threadIdx.x + u * 256, hp = i / 3, c3 = i - hp * 3, yrow = hp / HW, xh = hp - yrow * HW;
-      const __bf16 b = (__bf16)ra[u];
-      const unsigned short bits = __builtin_bit_cast(unsigned short, b);
-#pragma unroll
-      for (int j = 0; j < (S == 1 ? 5 : 3); ++j) {
-        const int kx = S == 1 ? j : (xh & 1) + 2 * j;   // S = 2: only the taps of this column's parity see it
-        const int d = xh - kx, xp = S == 1 ? d : d >> 1;
-        const bool ok = i < HH * HW * 3 && kx < 5 && d >= 0 && xp < 16;
-        const int off = ok ? ((c3 * 5 + kx) * HH + yrow) * 32 + xp * 2 : PL_DUMP + (int)threadIdx.x * 2;
-        *reinterpret_cast<unsigned short*>(sP + off) = bits;
-      }
+      const int hp = threadIdx.x + u * 256;
+      if (hp < HH * HW)
+        *reinterpret_cast<bf16x4*>(sH + hp * 8) = bf16x4{(__bf16)ra[u][0], (__bf16)ra[u][1], (__bf16)ra[u][2], (__bf16)0.f};
     }
   };
   if ((int)blockIdx.x < ntiles) tile_load(blockIdx.x);
@@ -340,45 +334,52 @@ __global__ __launch_bounds__(256, NT == 2 ? LG_N3W_LB : 1) void n3_wgrad16_kerne
     tile_store();
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) tile_load(tile + gridDim.x);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
     for (int ks = 0; ks < KSW; ++ks) {
       const int ly = KSW * kw + ks;  // tile row = the 16 pixels of this k step
-      bf16x8 a[3], b[NTW];
+      bf16x8 a[4], b[NTW];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) a[i] = *reinterpret_cast<const bf16x8*>(sP + aoff[i] + s * ly * 32);
+      for (int i = 0; i < 4; ++i) {
+        // (rows >= 100: both halves come out of the zero region; s * 32 bytes on is still inside it)
+        const char* pa = sH + aoff[i] + (aoff[i] == ZOFF ? 0 : s * ly * HW * 8);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pa + s * 32));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        a[i] = __builtin_bit_cast(bf16x8, v);
+      }
       const int row0 = ly * TW + 8 * (g >> 1) + lq;
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         const char* pb = sB + row0 * RSB + ((chw * NTW + j) * 32 + colbase) * 2;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb + 4 * RSB));
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         b[j] = __builtin_bit_cast(bf16x8, v);
       }
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
           if constexpr (!(LG_N3W_DBG & 8)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
           else acc[i][j][0] += (float)a[i][0] * (float)b[j][0];
         }
     }
-    if constexpr ((LG_N3W_DBG & 1) != 0) { if (ra[0] == 12345.678f) sP[threadIdx.x] = 1; }   // keeps the 3-channel loads alive
+    if constexpr ((LG_N3W_DBG & 1) != 0) { if (ra[0][0] == 12345.678f) sH[threadIdx.x] = 1; }   // keeps the 3-channel loads alive
   }
   float* mrg = reinterpret_cast<float*>(sB);  // merge the waves' pixel shares in order (sB is dead), one slab per block
   for (int w = 0; w < (CSPLIT ? 2 : 4); ++w) {
     __syncthreads();
     if (kw == w) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (row < 75) {
-              float* q = mrg + row * Cs + (chw * NTW + j) * 32 + r;
+            const int m = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;   // (tap, c4): tap = m / 4, c4 = e & 3
+            if (m < 100 && (e & 3) < 3) {
+              float* q = mrg + ((m >> 2) * 3 + (e & 3)) * Cs + (chw * NTW + j) * 32 + r;
               *q = (w == 0 ? 0.f : *q) + acc[i][j][e];
             }
           }
@@ -485,10 +486,10 @@ extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void
   }
   float* slab = (float*)workspace;
   if (s16 && !lg_env_flag("LG_N3W_F32")) {  // bf16 path: bf16 MFMA straight from the mirror
-    // LDS: the wide operand's tile (also the merge buffer) + the 15 shifted planes, their zero rows and the dump slots
+    // LDS: the wide operand's tile (also the merge buffer) + the bf16 RGBx halo of the 3-channel operand and its zero region
     auto ldsz = [&](int cs, int th = 8) {
       const size_t sb = (size_t)th * 16 * (cs * 2 + 16), mg = (size_t)75 * cs * 4;
-      return (sb > mg ? sb : mg) + (size_t)15 * (s * th + 4) * 32 + (size_t)(s * th + 1) * 32 + 512;
+      return (sb > mg ? sb : mg) + (size_t)(s * th + 4) * (s * 16 + 4) * 8 + 64 + (size_t)s * 32 + 64;   // + the RGBx halo and its zero region
     };
     if (th16) hipLaunchKernelGGL((n3_wgrad16_kernel<1, 16, 1>), dim3(nblk), dim3(256), ldsz(32, 16), st, big3, s16, slab, B, H, W, s, pad);
     else if (Cs == 32 && s == 1) hipLaunchKernelGGL((n3_wgrad16_kernel<1, 8, 1>), dim3(nblk), dim3(256), ldsz(32), st, big3, s16, slab, B, H, W, s, pad);
