@@ -192,6 +192,9 @@ __global__ __launch_bounds__(256) void up_p16_kernel(const __bf16* __restrict__ 
 // the C tiles go through LDS and leave as 16-B-per-lane stores of whole contiguous rows; the conv1 form also emits
 // the per-block InstanceNorm moments {count, mean, M2} (same record as conv_halo.hip) so no pass re-reads z.
 // --------------------------------------------------------------------------------------------------------------
+#ifndef LG_P16_DBG
+#define LG_P16_DBG 0   // compile-time ablation bits (timing only, results wrong): 1 no image loads, 2 no output stores, 4 no MFMA, 8 no moments
+#endif
 template <int S, int N, bool OUT16, bool STATS, bool FUSE = false>
 __global__ __launch_bounds__(256, N == 64 ? 3 : 4) void patch_p16_kernel(const float* __restrict__ src, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out,
@@ -249,7 +252,8 @@ __global__ __launch_bounds__(256, N == 64 ? 3 : 4) void patch_p16_kernel(const f
       hv[u][0] = 0.f; hv[u][1] = 0.f; hv[u][2] = 0.f;
       if (i < HSIDE * HSIDE && (unsigned)sy < (unsigned)Hs && (unsigned)sx < (unsigned)Ws) {
         const float* q = src + ((long long)(n * Hs + sy) * Ws + sx) * 3;
-        hv[u][0] = q[0]; hv[u][1] = q[1]; hv[u][2] = q[2];
+        if constexpr (!(LG_P16_DBG & 1)) { hv[u][0] = q[0]; hv[u][1] = q[1]; hv[u][2] = q[2]; }
+        else { hv[u][0] = (float)sy; hv[u][1] = (float)sx; }
       }
     }
   };
@@ -310,14 +314,17 @@ __global__ __launch_bounds__(256, N == 64 ? 3 : 4) void patch_p16_kernel(const f
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], bf[ks][nt], acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) {
+          if constexpr (!(LG_P16_DBG & 4)) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], bf[ks][nt], acc[nt], 0, 0, 0);
+          else acc[nt][0] += (float)a[ks][0] * (float)bf[ks][nt][0];
+        }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int e2 = 0; e2 < 2; ++e2) {   // two accumulator rows at a time: v_pk_add_f32 / v_pk_fma_f32 halve the VALU count
           f32x2 v = {acc[nt][2 * e2], acc[nt][2 * e2 + 1]};
           if constexpr (HAS_BIAS) v += f32x2{bv[nt], bv[nt]};
-          if constexpr (STATS) {
+          if constexpr (STATS && !(LG_P16_DBG & 8)) {
             const f32x2 d = v - f32x2{shift, shift};
             s1v += d;
             s2v = __builtin_elementwise_fma(d, d, s2v);
@@ -335,7 +342,8 @@ __global__ __launch_bounds__(256, N == 64 ? 3 : 4) void patch_p16_kernel(const f
           bf16x8 v;
           v[0] = (__bf16)a[0]; v[1] = (__bf16)a[1]; v[2] = (__bf16)a[2]; v[3] = (__bf16)a[3];
           v[4] = (__bf16)b[0]; v[5] = (__bf16)b[1]; v[6] = (__bf16)b[2]; v[7] = (__bf16)b[3];
-          *reinterpret_cast<bf16x8*>(out16 + o0 + idx * 8) = v;
+          if constexpr (!(LG_P16_DBG & 2)) *reinterpret_cast<bf16x8*>(out16 + o0 + idx * 8) = v;
+          else if (v[0] == (__bf16)12345.f) *reinterpret_cast<bf16x8*>(out16 + o0 + idx * 8) = v;
           if constexpr (FUSE) {
             const lg_const_f32p sp = lg_as_const(nf.stats + (long long)n * 8);   // scalar loads (lg_common.h)
             lg_nf_accum(__builtin_bit_cast(u32x4, v), zpre[i * NQZ + q], sp[0], sp[4], sp[2], sp[3], nf.alpha, nf1, nf2);
