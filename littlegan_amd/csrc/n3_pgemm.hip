@@ -196,21 +196,27 @@ __global__ __launch_bounds__(256) void up_p16_kernel(const __bf16* __restrict__ 
 #define LG_P16_DBG 0   // compile-time ablation bits (timing only, results wrong): 1 no image loads, 2 no output stores, 4 no MFMA, 8 no moments
 #endif
 template <int S, int N, bool OUT16, bool STATS, bool FUSE = false>
-__global__ __launch_bounds__(256, N == 64 ? 3 : 4) void patch_p16_kernel(const float* __restrict__ src, const float* __restrict__ w,
+__global__ __launch_bounds__(256, 4) void patch_p16_kernel(const float* __restrict__ src, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         __bf16* __restrict__ out16, double* __restrict__ spart, int B,
                                                         int H, int W, int pad, LgNormFuse nf = LgNormFuse{}) {
   static_assert(!FUSE || (OUT16 && !STATS), "norm-backward sums: bf16 data-gradient form only");
-  constexpr int NT = N / 16, HSIDE = S * (TS - 1) + 5, PW = (HSIDE + 2) & ~1, TROWS = HSIDE + 1, NKS = 4;
-  constexpr int MTW = TS / 4;  // m-tiles (tile rows of 16 pixels) per wave
+  // 64 columns: the waves split the CHANNELS as well as the tile rows (wave w: channel half w & 1, rows 8 (w >> 1) .. + 7) — half the
+  // resident weight fragments per wave, four blocks per CU instead of three (round 4: the kernel follows its occupancy, not its
+  // instruction count — every ablation that freed registers gained, the rewrite of the fragment build alone did not)
+  constexpr bool CSPLIT = N == 64;
+  constexpr int NWC = CSPLIT ? N / 2 : N;          // channels per wave
+  constexpr int NT = NWC / 16, HSIDE = S * (TS - 1) + 5, PW = (HSIDE + 2) & ~1, TROWS = HSIDE + 1, NKS = 4;
+  constexpr int MTW = CSPLIT ? TS / 2 : TS / 4;  // m-tiles (tile rows of 16 pixels) per wave
   constexpr bool HAS_BIAS = S == 2;   // the stride-1 form is the final layer's data gradient: no bias term
   // TROWS x PW pixels of 8 bytes; row HSIDE and the pixels right of column HSIDE - 1 stay zero (touched by zero-weight slots only)
   __shared__ __attribute__((aligned(16))) bf16x4 tile[TROWS * PW];
-  __shared__ __attribute__((aligned(16))) float cst[4][16 * N];
+  __shared__ __attribute__((aligned(16))) float cst[4][16 * NWC];
   __shared__ double sred[40];
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, g = lane >> 4;
   const int tpx = W / TS, tpi = tpx * (H / TS), ntiles = B * tpi;
   const int Hs = S * H, Ws = S * W;
+  const int chw = CSPLIT ? (wid & 1) : 0, rw = CSPLIT ? (wid >> 1) : wid;   // channel half, row group of this wave
 
   // B fragments (constant for the block): lane (n = l&15, g) holds k' = 32 ks + 8 g + j = 24 ky + 4 kx + c4
   bf16x8 bf[NKS][NT];
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(256, N == 64 ? 3 : 4) void patch_p16_kernel(const f
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int kp = 32 * ks + 8 * g + j, ky = kp / 24, rem = kp - 24 * ky, kx = rem >> 2, c4 = rem & 3;
-        v[j] = (ky < 5 && kx < 5 && c4 < 3) ? (__bf16)w[(long long)(ky * 15 + kx * 3 + c4) * N + nt * 16 + r] : (__bf16)0.f;
+        v[j] = (ky < 5 && kx < 5 && c4 < 3) ? (__bf16)w[(long long)(ky * 15 + kx * 3 + c4) * N + chw * NWC + nt * 16 + r] : (__bf16)0.f;
       }
       bf[ks][nt] = v;
     }
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(256, N == 64 ? 3 : 4) void patch_p16_kernel(const f
   }
   float bv[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bv[nt] = bias ? bias[nt * 16 + r] : 0.f;
+  for (int nt = 0; nt < NT; ++nt) bv[nt] = bias ? bias[chw * NWC + nt * 16 + r] : 0.f;
   for (int i = threadIdx.x; i < TROWS * PW; i += 256) tile[i] = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
 
   // the halo of the NEXT tile is requested (global -> registers) before this tile's MFMAs and written to LDS behind them:
@@ -293,11 +299,11 @@ __global__ __launch_bounds__(256, N == 64 ? 3 : 4) void patch_p16_kernel(const f
       for (int i = 0; i < MTW; ++i)
 #pragma unroll
         for (int q = 0; q < NQZ; ++q)
-          zpre[i * NQZ + q] = *reinterpret_cast<const u32x4*>(nf.z + ((long long)(n * H + y0 + wid * MTW + i) * W + x0) * N + (q * 64 + lane) * 8);
+          zpre[i * NQZ + q] = *reinterpret_cast<const u32x4*>(nf.z + ((long long)(n * H + y0 + rw * MTW + i) * W + x0) * N + (q * 64 + lane) * 8);
     }
     auto mtile = [&](auto i_c) {
       const int i = i_c;   // FUSE: a compile-time constant (the prefetched pieces are registers, not a runtime-indexed array)
-      const int ly = wid * MTW + i;
+      const int ly = rw * MTW + i;
       f32x4 acc[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -329,21 +335,22 @@ __global__ __launch_bounds__(256, N == 64 ? 3 : 4) void patch_p16_kernel(const f
             s1v += d;
             s2v = __builtin_elementwise_fma(d, d, s2v);
           }
-          cw[(4 * g + 2 * e2) * N + nt * 16 + r] = v[0];  // C layout: col = lane&15, row = 4(lane>>4)+e
-          cw[(4 * g + 2 * e2 + 1) * N + nt * 16 + r] = v[1];
+          cw[(4 * g + 2 * e2) * NWC + nt * 16 + r] = v[0];  // C layout: col = lane&15, row = 4(lane>>4)+e
+          cw[(4 * g + 2 * e2 + 1) * NWC + nt * 16 + r] = v[1];
         }
       __builtin_amdgcn_wave_barrier();
       const long long o0 = ((long long)(n * H + y0 + ly) * W + x0) * N;  // 16 pixels x N contiguous
       if constexpr (OUT16) {
 #pragma unroll
-        for (int q = 0; q < 16 * N / 8 / 64; ++q) {
+        for (int q = 0; q < 16 * NWC / 8 / 64; ++q) {
           const int idx = q * 64 + lane;
+          const int gix = CSPLIT ? (idx / (NWC / 8)) * N + chw * NWC + (idx % (NWC / 8)) * 8 : idx * 8;   // element offset inside the 16-pixel row segment
           const f32x4 a = *reinterpret_cast<const f32x4*>(cw + idx * 8), b = *reinterpret_cast<const f32x4*>(cw + idx * 8 + 4);
           bf16x8 v;
           v[0] = (__bf16)a[0]; v[1] = (__bf16)a[1]; v[2] = (__bf16)a[2]; v[3] = (__bf16)a[3];
           v[4] = (__bf16)b[0]; v[5] = (__bf16)b[1]; v[6] = (__bf16)b[2]; v[7] = (__bf16)b[3];
-          if constexpr (!(LG_P16_DBG & 2)) *reinterpret_cast<bf16x8*>(out16 + o0 + idx * 8) = v;
-          else if (v[0] == (__bf16)12345.f) *reinterpret_cast<bf16x8*>(out16 + o0 + idx * 8) = v;
+          if constexpr (!(LG_P16_DBG & 2)) *reinterpret_cast<bf16x8*>(out16 + o0 + gix) = v;
+          else if (v[0] == (__bf16)12345.f) *reinterpret_cast<bf16x8*>(out16 + o0 + gix) = v;
           if constexpr (FUSE) {
             const lg_const_f32p sp = lg_as_const(nf.stats + (long long)n * 8);   // scalar loads (lg_common.h)
             lg_nf_accum(__builtin_bit_cast(u32x4, v), zpre[i * NQZ + q], sp[0], sp[4], sp[2], sp[3], nf.alpha, nf1, nf2);
@@ -351,9 +358,10 @@ __global__ __launch_bounds__(256, N == 64 ? 3 : 4) void patch_p16_kernel(const f
         }
       } else {
 #pragma unroll
-        for (int q = 0; q < 16 * N / 4 / 64; ++q) {
+        for (int q = 0; q < 16 * NWC / 4 / 64; ++q) {
           const int idx = q * 64 + lane;
-          *reinterpret_cast<f32x4*>(out + o0 + idx * 4) = *reinterpret_cast<const f32x4*>(cw + idx * 4);
+          const int gix = CSPLIT ? (idx / (NWC / 4)) * N + chw * NWC + (idx % (NWC / 4)) * 4 : idx * 4;
+          *reinterpret_cast<f32x4*>(out + o0 + gix) = *reinterpret_cast<const f32x4*>(cw + idx * 4);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(256, N == 64 ? 3 : 4) void patch_p16_kernel(const f
     if constexpr (FUSE) {   // unrolled: the prefetched pieces are registers, not a runtime-indexed array
       mtile(std::integral_constant<int, 0>{}); mtile(std::integral_constant<int, 1>{});
       mtile(std::integral_constant<int, 2>{}); mtile(std::integral_constant<int, 3>{});
-      static_assert(MTW == 4, "four tile rows per wave");
+      static_assert(MTW == 4 && !CSPLIT, "four tile rows per wave");
     } else {
 #pragma unroll 1
       for (int i = 0; i < MTW; ++i) mtile(i);   // a runtime row index: one copy of the body
@@ -441,7 +449,7 @@ extern "C" int lg_n3_conv1_fwd_p16_try(const float* img, const float* w, const f
   if (H % TS || W % TS || N != 64 || !img || !w || (!z && !z16)) return LG_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int tpi = (H / TS) * (W / TS), ntiles = B * tpi;
-  const dim3 grid(patch_grid(ntiles, 3));  // 160 VGPRs: 3 blocks per CU (measured 4096 / 2048 / 1024 / 768 / 512 blocks: 93 / 75 / 72 / 59 / 66 us)
+  const dim3 grid(patch_grid(ntiles, 4));  // channel-split waves, <= 128 VGPRs: 4 blocks per CU (round 3, 160 VGPRs: 4096 / 2048 / 1024 / 768 / 512 blocks: 93 / 75 / 72 / 59 / 66 us)
   const bool stats = spart && nparts && (size_t)B * tpi * 3 * sizeof(double) <= spart_bytes;
   if (z16) {  // bf16 activation path: z leaves as bf16 (the moments still come from the fp32 accumulators)
     if (stats) hipLaunchKernelGGL((patch_p16_kernel<2, 64, true, true>), grid, dim3(256), 0, st, img, w, bias, nullptr, (__bf16*)z16, (double*)spart, B, H, W, 1);
