@@ -34,7 +34,9 @@ __global__ __launch_bounds__(256) void n3_s1t_fwd_kernel(const float* __restrict
   }
   __syncthreads();
   const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
-  float acc[3] = {bias[0], bias[1], bias[2]};
+  // two channels per instruction (v_pk_fma_f32, exact fp32 products as before): even channels add up in lane 0 of a pair, odd ones in
+  // lane 1 — the kernel was bound by its 2400 scalar FMAs per pixel (9.6 k issue cycles per wave against 0.8 k of LDS reads)
+  f32x2 acc[3] = {f32x2{bias[0], 0.f}, f32x2{bias[1], 0.f}, f32x2{bias[2], 0.f}};
 #pragma unroll 1
   for (int ky = 0; ky < 5; ++ky) {
 #pragma unroll
@@ -48,14 +50,14 @@ __global__ __launch_bounds__(256) void n3_s1t_fwd_kernel(const float* __restrict
 #pragma unroll
         for (int co = 0; co < 3; ++co) {
           const float* wc = wt + co * C + c4 * 4;
-          acc[co] = fmaf(v[0], wc[0], acc[co]); acc[co] = fmaf(v[1], wc[1], acc[co]);
-          acc[co] = fmaf(v[2], wc[2], acc[co]); acc[co] = fmaf(v[3], wc[3], acc[co]);
+          acc[co] = __builtin_elementwise_fma(f32x2{v[0], v[1]}, f32x2{wc[0], wc[1]}, acc[co]);
+          acc[co] = __builtin_elementwise_fma(f32x2{v[2], v[3]}, f32x2{wc[2], wc[3]}, acc[co]);
         }
       }
     }
   }
   float* o = y + ((long long)(n * H + y0 + ly) * W + x0 + lx) * 3;
-  o[0] = tanhf(acc[0]); o[1] = tanhf(acc[1]); o[2] = tanhf(acc[2]);
+  o[0] = tanhf(acc[0][0] + acc[0][1]); o[1] = tanhf(acc[1][0] + acc[1][1]); o[2] = tanhf(acc[2][0] + acc[2][1]);
 }
 
 // one thread per SOURCE pixel q of a 16x16 tile; it owns the 2x2 output quad (4 parity classes x 3 channels)
@@ -68,9 +70,9 @@ __global__ __launch_bounds__(256) void n3_up_kernel(const float* __restrict__ sr
   const int n = blockIdx.x / tpi, tt = blockIdx.x % tpi;
   const int y0 = (tt / tpx) * TS, x0 = (tt % tpx) * TS;
   const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
-  float acc[4][3];
+  f32x2 acc[4][3];   // (even channels, odd channels): v_pk_fma_f32, see n3_s1t_fwd_kernel
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { acc[k][0] = 0.f; acc[k][1] = 0.f; acc[k][2] = 0.f; }
+  for (int k = 0; k < 4; ++k) { acc[k][0] = f32x2{0.f, 0.f}; acc[k][1] = f32x2{0.f, 0.f}; acc[k][2] = f32x2{0.f, 0.f}; }
   for (int c0 = 0; c0 < C; c0 += CK) {
     __syncthreads();
     for (int i = threadIdx.x; i < HS * HS * (CK / 4); i += 256) {
@@ -98,8 +100,9 @@ __global__ __launch_bounds__(256) void n3_up_kernel(const float* __restrict__ sr
 #pragma unroll
           for (int co = 0; co < 3; ++co) {
             const float* wc = wt + co * C + c4 * 4;
-            float a = acc[cls][co];
-            a = fmaf(v[0], wc[0], a); a = fmaf(v[1], wc[1], a); a = fmaf(v[2], wc[2], a); a = fmaf(v[3], wc[3], a);
+            f32x2 a = acc[cls][co];
+            a = __builtin_elementwise_fma(f32x2{v[0], v[1]}, f32x2{wc[0], wc[1]}, a);
+            a = __builtin_elementwise_fma(f32x2{v[2], v[3]}, f32x2{wc[2], wc[3]}, a);
             acc[cls][co] = a;
           }
         }
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void n3_up_kernel(const float* __restrict__ sr
 #pragma unroll
     for (int px = 0; px < 2; ++px)
 #pragma unroll
-      for (int co = 0; co < 3; ++co) o[px * 3 + co] = acc[py * 2 + px][co];
+      for (int co = 0; co < 3; ++co) o[px * 3 + co] = acc[py * 2 + px][co][0] + acc[py * 2 + px][co][1];
   }
 }
 
