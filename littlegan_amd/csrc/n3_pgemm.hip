@@ -16,6 +16,9 @@
 #include <type_traits>
 #include "lg_common.h"
 
+#ifndef LG_P16_DBG
+#define LG_P16_DBG 0   // compile-time ablation bits (timing only, results wrong).  patch_p16: 1 no image loads, 2 no output stores, 4 no MFMA, 8 no moments;
+#endif                 // up_p16: 16 no shift-sum reads, 32 no product writes, 64 no source loads, 128 no barriers inside a tile
 namespace {
 
 constexpr int TS = 16;  // tile side (pixels of the M grid)
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void up_p16_kernel(const __bf16* __restrict__ 
       const bool ok = q < NQ && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
 #pragma unroll
       for (int kh = 0; kh < KH; ++kh)
-        af[i][kh] = ok ? *reinterpret_cast<const bf16x8*>(src16 + ((long long)(n * H + sy) * W + sx) * C + kh * 32 + g * 8) : zero8();
+        af[i][kh] = (ok && !(LG_P16_DBG & 64)) ? *reinterpret_cast<const bf16x8*>(src16 + ((long long)(n * H + sy) * W + sx) * C + kh * 32 + g * 8) : zero8();
     }
   };
   const int ly = threadIdx.x / TS, lx = threadIdx.x % TS;
@@ -139,19 +142,22 @@ __global__ __launch_bounds__(256) void up_p16_kernel(const __bf16* __restrict__ 
 #pragma unroll
           for (int kh = 0; kh < KH; ++kh) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kh], bf[ky][kh], c, 0, 0, 0);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) sP[(mt * 16 + 4 * g + e) * PR + r] = c[e];
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (!(LG_P16_DBG & 32)) sP[(mt * 16 + 4 * g + e) * PR + r] = c[e];
+            else if (c[e] == 12345.f) sP[(mt * 16 + 4 * g + e) * PR + r] = c[e];
+          }
         }
       }
-      __syncthreads();
+      if constexpr (!(LG_P16_DBG & 128)) __syncthreads();
       // out[2q+p] += src[q + d] W[k],  p = 1 - (k & 1),  d = (p + 1 - k) / 2   (conv2d_backprop_input, SAME, s=2, k=5)
       const int py = 1 - (ky & 1), dy = (py + 1 - ky) / 2;
 #pragma unroll
-      for (int kx = 0; kx < 5; ++kx) {
+      for (int kx = 0; kx < ((LG_P16_DBG & 16) ? 1 : 5); ++kx) {
         const int px = 1 - (kx & 1), dx = (px + 1 - kx) / 2;
         const float* pp = sP + ((ly + 1 + dy) * HS + (lx + 1 + dx)) * PR + kx * 3;
         acc[py * 2 + px][0] += pp[0]; acc[py * 2 + px][1] += pp[1]; acc[py * 2 + px][2] += pp[2];
       }
-      __syncthreads();
+      if constexpr (!(LG_P16_DBG & 128)) __syncthreads();
     }
     const int yq = y0 + ly, xq = x0 + lx;
 #pragma unroll
@@ -192,9 +198,6 @@ __global__ __launch_bounds__(256) void up_p16_kernel(const __bf16* __restrict__ 
 // the C tiles go through LDS and leave as 16-B-per-lane stores of whole contiguous rows; the conv1 form also emits
 // the per-block InstanceNorm moments {count, mean, M2} (same record as conv_halo.hip) so no pass re-reads z.
 // --------------------------------------------------------------------------------------------------------------
-#ifndef LG_P16_DBG
-#define LG_P16_DBG 0   // compile-time ablation bits (timing only, results wrong): 1 no image loads, 2 no output stores, 4 no MFMA, 8 no moments
-#endif
 template <int S, int N, bool OUT16, bool STATS, bool FUSE = false>
 __global__ __launch_bounds__(256, 4) void patch_p16_kernel(const float* __restrict__ src, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out,
