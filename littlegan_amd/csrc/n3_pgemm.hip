@@ -101,7 +101,11 @@ __global__ __launch_bounds__(256) void s1t_fwd_p16_kernel(const __bf16* __restri
 
 // one thread per SOURCE pixel q of a 16x16 tile; it owns the 2x2 output quad (4 parity classes x 3 channels)
 template <int C>
-__global__ __launch_bounds__(256) void up_p16_kernel(const __bf16* __restrict__ src16, const float* __restrict__ w,
+#ifndef LG_UP16_SINGLE
+#define LG_UP16_SINGLE 0   // A/B builds: 1 = one A-fragment set (no tile-ahead prefetch), compiled for three blocks per CU (168 VGPRs).
+                           // Round 4, same box, LG_PATCH_GRID=768: 58.0 against 64.4 us at B = 256, 119.9 against 117.1 at 2B — not adopted
+#endif
+__global__ __launch_bounds__(256, LG_UP16_SINGLE ? 3 : 1) void up_p16_kernel(const __bf16* __restrict__ src16, const float* __restrict__ w,
                                                      float* __restrict__ out, int B, int H, int W) {
   constexpr int HS = TS + 2, NQ = HS * HS, NMT = (NQ + 15) / 16, MTW = (NMT + 3) / 4, KH = C / 32;
   __shared__ float sP[NMT * 16 * PR];
@@ -169,6 +173,11 @@ __global__ __launch_bounds__(256) void up_p16_kernel(const __bf16* __restrict__ 
         for (int co = 0; co < 3; ++co) o[px * 3 + co] = acc[py * 2 + px][co];
     }
   };
+#if LG_UP16_SINGLE
+  bf16x8 afS[MTW][KH];
+  for (int t = blockIdx.x; t < ntiles; t += G) { load_af(t, afS); compute(t, afS); }
+  return;
+#endif
   bf16x8 afA[MTW][KH], afB[MTW][KH];
   int t = blockIdx.x;
   if (t < ntiles) load_af(t, afA);
