@@ -332,11 +332,20 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
 typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
 struct f32x8 { f32x4 lo, hi; };
 
-template <bool IS16>
+// Non-temporal accesses of the bf16 passes (bits: 1 backward-apply loads, 2 backward-apply stores, 4 apply loads, 8 apply stores).
+// z, g and the skip map are dead behind these passes (z is read again only a whole tape later): loaded non-temporally they stop evicting
+// what the neighbouring conv kernels live on (their sources and weights in L2 / the Infinity Cache).  Round 4, whole step on one box,
+// variant builds, two rounds: 11.15 / 11.17 ms (0) -> 11.06 / 11.07 (1) -> 10.98 / 10.97 (5) = -1.6 %; the stores (3, 7: 11.07 / 10.98) add
+// nothing there — although the passes in isolation (scripts/bench_norm.py) show the opposite: stores -9 .. -13 %, loads nothing.
+#ifndef LG_NORM_NT
+#define LG_NORM_NT 5
+#endif
+template <bool IS16, bool NT = false>
 __device__ __forceinline__ f32x8 load8(const void* p, long long i8) {  // elements [8*i8, 8*i8 + 8)
   f32x8 r;
   if constexpr (IS16) {
-    const bf16x8v w = *reinterpret_cast<const bf16x8v*>(reinterpret_cast<const __bf16*>(p) + i8 * 8);
+    const bf16x8v* q = reinterpret_cast<const bf16x8v*>(reinterpret_cast<const __bf16*>(p) + i8 * 8);
+    const bf16x8v w = NT ? __builtin_nontemporal_load(q) : *q;
     r.lo = f32x4{(float)w[0], (float)w[1], (float)w[2], (float)w[3]};
     r.hi = f32x4{(float)w[4], (float)w[5], (float)w[6], (float)w[7]};
   } else {
@@ -346,11 +355,13 @@ __device__ __forceinline__ f32x8 load8(const void* p, long long i8) {  // elemen
   }
   return r;
 }
+template <bool NT = false>
 __device__ __forceinline__ void store8_bf16(__bf16* p, long long i8, const f32x8& v) {
   bf16x8v w;
   w[0] = (__bf16)v.lo[0]; w[1] = (__bf16)v.lo[1]; w[2] = (__bf16)v.lo[2]; w[3] = (__bf16)v.lo[3];
   w[4] = (__bf16)v.hi[0]; w[5] = (__bf16)v.hi[1]; w[6] = (__bf16)v.hi[2]; w[7] = (__bf16)v.hi[3];
-  *reinterpret_cast<bf16x8v*>(p + i8 * 8) = w;
+  if constexpr (NT) __builtin_nontemporal_store(w, reinterpret_cast<bf16x8v*>(p + i8 * 8));
+  else *reinterpret_cast<bf16x8v*>(p + i8 * 8) = w;
 }
 __device__ __forceinline__ void store8_f32(float* p, long long i8, const f32x8& v) {
   *reinterpret_cast<f32x4*>(p + i8 * 8) = v.lo;
@@ -451,9 +462,9 @@ __global__ __launch_bounds__(256) void apply16p_kernel(const __bf16* __restrict_
     for (int u = 0; u < EW8_UNR; ++u) {
       const unsigned i = i0 + u * 256;
       if (i < L8) {
-        v[u] = load8<true>(x, base + i);
-        if constexpr (SK == 1) sk[u] = load8<false>(skip, base + i);
-        if constexpr (SK == 2) sk[u] = load8<true>(skip, base + i);
+        v[u] = load8<true, (LG_NORM_NT & 4) != 0>(x, base + i);
+        if constexpr (SK == 1) sk[u] = load8<false, (LG_NORM_NT & 4) != 0>(skip, base + i);
+        if constexpr (SK == 2) sk[u] = load8<true, (LG_NORM_NT & 4) != 0>(skip, base + i);
       }
     }
 #pragma unroll
@@ -469,7 +480,7 @@ __global__ __launch_bounds__(256) void apply16p_kernel(const __bf16* __restrict_
         if (k < 4) v[u].lo[k & 3] = t; else v[u].hi[k & 3] = t;
       }
       if (y) store8_f32(y, base + i, v[u]);
-      if (y16) store8_bf16(y16, base + i, v[u]);
+      if (y16) store8_bf16<(LG_NORM_NT & 8) != 0>(y16, base + i, v[u]);
     }
   }
 }
@@ -543,7 +554,7 @@ __global__ __launch_bounds__(256) void bwd_apply16_kernel(const __bf16* __restri
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const unsigned i = i0 + u * ustep;
-      if (i < tot) { xs[u] = load8<true>(x, i); gs[u] = load8<G16>(g, i); }
+      if (i < tot) { xs[u] = load8<true, (LG_NORM_NT & 1) != 0>(x, i); gs[u] = load8<G16, (LG_NORM_NT & 1) != 0>(g, i); }
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -567,7 +578,7 @@ __global__ __launch_bounds__(256) void bwd_apply16_kernel(const __bf16* __restri
         if (k < 4) o.lo[k & 3] = d; else o.hi[k & 3] = d;
       }
       if (dx) store8_f32(dx, i, o);
-      if (dx16) store8_bf16(dx16, i, o);
+      if (dx16) store8_bf16<(LG_NORM_NT & 2) != 0>(dx16, i, o);
       if constexpr (DB) { csum.lo += o.lo; csum.hi += o.hi; }
     }
   }
