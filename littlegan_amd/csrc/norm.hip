@@ -337,6 +337,8 @@ struct f32x8 { f32x4 lo, hi; };
 // what the neighbouring conv kernels live on (their sources and weights in L2 / the Infinity Cache).  Round 4, whole step on one box,
 // variant builds, two rounds: 11.15 / 11.17 ms (0) -> 11.06 / 11.07 (1) -> 10.98 / 10.97 (5) = -1.6 %; the stores (3, 7: 11.07 / 10.98) add
 // nothing there — although the passes in isolation (scripts/bench_norm.py) show the opposite: stores -9 .. -13 %, loads nothing.
+// The same treatment of the final layer's input rows, the final weight gradient's activation operand and up_p16's source (their
+// last readers) moved the step by nothing (10.79 - 10.86 against 10.81 - 10.90 ms): removed.
 #ifndef LG_NORM_NT
 #define LG_NORM_NT 5
 #endif
