@@ -102,6 +102,19 @@ __global__ __launch_bounds__(64) void stats_final_kernel(const double* __restric
   }
 }
 
+// Non-temporal accesses of the element-wise passes, bf16 and fp32 path alike (bits: 1 backward-apply loads, 2 backward-apply stores, 4 apply loads, 8 apply stores).
+// z, g and the skip map are dead behind these passes (z is read again only a whole tape later): loaded non-temporally they stop evicting
+// what the neighbouring conv kernels live on (their sources and weights in L2 / the Infinity Cache).  Round 4, whole step on one box,
+// variant builds, two rounds: 11.15 / 11.17 ms (0) -> 11.06 / 11.07 (1) -> 10.98 / 10.97 (5) = -1.6 %; the stores (3, 7: 11.07 / 10.98) add
+// nothing there — although the passes in isolation (scripts/bench_norm.py) show the opposite: stores -9 .. -13 %, loads nothing.
+// The same treatment of the final layer's input rows, the final weight gradient's activation operand and up_p16's source (their
+// last readers) moved the step by nothing (10.79 - 10.86 against 10.81 - 10.90 ms): removed.
+#ifndef LG_NORM_NT
+#define LG_NORM_NT 5
+#endif
+template <bool NT, typename V>
+__device__ __forceinline__ V lg_ld(const V* q) { if constexpr (NT) return __builtin_nontemporal_load(q); else return *q; }
+
 __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                     const float* __restrict__ skip, float* __restrict__ y,
                                                     __bf16* __restrict__ y16, long long L4, long long total4,
@@ -115,8 +128,8 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ x,
     for (int u = 0; u < EW_UNR; ++u) {
       const unsigned i = i0 + u * 256;
       if (i < tot) {
-        v[u] = *reinterpret_cast<const f32x4*>(x + (long long)i * 4);
-        if (skip) sk[u] = *reinterpret_cast<const f32x4*>(skip + (long long)i * 4);
+        v[u] = lg_ld<(LG_NORM_NT & 4) != 0>(reinterpret_cast<const f32x4*>(x + (long long)i * 4));
+        if (skip) sk[u] = lg_ld<(LG_NORM_NT & 4) != 0>(reinterpret_cast<const f32x4*>(skip + (long long)i * 4));
       }
     }
 #pragma unroll
@@ -144,12 +157,13 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ x,
   }
 }
 
+template <bool NT = false>
 __device__ __forceinline__ f32x4 load_g4(const void* g, long long i4, int g16) {  // 4 gradient values, fp32 or bf16 storage
   if (g16) {
-    const bf16x4 w = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(g) + i4);
+    const bf16x4 w = lg_ld<NT>(reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(g) + i4));
     return f32x4{(float)w[0], (float)w[1], (float)w[2], (float)w[3]};
   }
-  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g) + i4);
+  return lg_ld<NT>(reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g) + i4));
 }
 
 // partial[n][chunk] = {sum dz, sum dz*c} (doubles)
@@ -275,8 +289,8 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
    for (int u = 0; u < UNR; ++u) {
      const unsigned i = i0 + u * 256;
      if (i < tot) {
-       xs[u] = *reinterpret_cast<const f32x4*>(x + (long long)i * 4);
-       gs[u] = load_g4(g, (long long)i * 4, g16);
+       xs[u] = lg_ld<(LG_NORM_NT & 1) != 0>(reinterpret_cast<const f32x4*>(x + (long long)i * 4));   // last reader of z and g
+       gs[u] = load_g4<(LG_NORM_NT & 1) != 0>(g, (long long)i * 4, g16);
      }
    }
 #pragma unroll
@@ -332,16 +346,6 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
 typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
 struct f32x8 { f32x4 lo, hi; };
 
-// Non-temporal accesses of the bf16 passes (bits: 1 backward-apply loads, 2 backward-apply stores, 4 apply loads, 8 apply stores).
-// z, g and the skip map are dead behind these passes (z is read again only a whole tape later): loaded non-temporally they stop evicting
-// what the neighbouring conv kernels live on (their sources and weights in L2 / the Infinity Cache).  Round 4, whole step on one box,
-// variant builds, two rounds: 11.15 / 11.17 ms (0) -> 11.06 / 11.07 (1) -> 10.98 / 10.97 (5) = -1.6 %; the stores (3, 7: 11.07 / 10.98) add
-// nothing there — although the passes in isolation (scripts/bench_norm.py) show the opposite: stores -9 .. -13 %, loads nothing.
-// The same treatment of the final layer's input rows, the final weight gradient's activation operand and up_p16's source (their
-// last readers) moved the step by nothing (10.79 - 10.86 against 10.81 - 10.90 ms): removed.
-#ifndef LG_NORM_NT
-#define LG_NORM_NT 5
-#endif
 template <bool IS16, bool NT = false>
 __device__ __forceinline__ f32x8 load8(const void* p, long long i8) {  // elements [8*i8, 8*i8 + 8)
   f32x8 r;
