@@ -112,6 +112,14 @@ __global__ __launch_bounds__(64) void stats_final_kernel(const double* __restric
 #ifndef LG_NORM_NT
 #define LG_NORM_NT 5
 #endif
+// The bf16 apply / backward-apply passes walk their maps from the END (bits: 1 apply16p, 2 bwd_apply16).  Their producers (the conv
+// kernels) write a map front to back and their consumers read it front to back: a pass in between that starts at the END meets what the
+// producer wrote last — still in the Infinity Cache when the map is larger than it — and leaves the START of its own output for the
+// consumer's first reads.  Round 4, whole step, one box, three rounds: 10.79 / 10.76 / 10.72 ms (0) against 10.75 / 10.66 / 10.64 (3),
+// captured 10.70 against 10.66; results unchanged except the bias column sums of a multi-trip backward pass (trip order).
+#ifndef LG_NORM_REV
+#define LG_NORM_REV 3
+#endif
 template <bool NT, typename V>
 __device__ __forceinline__ V lg_ld(const V* q) { if constexpr (NT) return __builtin_nontemporal_load(q); else return *q; }
 
@@ -432,7 +440,9 @@ __global__ __launch_bounds__(256) void apply16p_kernel(const __bf16* __restrict_
                                                        float* __restrict__ y, __bf16* __restrict__ y16, unsigned L8,
                                                        int post_leaky, float alpha) {
   __shared__ float sst[8];
-  const int n = blockIdx.y;
+  // (LG_NORM_REV & 1: samples and chunks from the end — the producer wrote the end of the map last, the consumer reads its start first)
+  const int n = (LG_NORM_REV & 1) ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+  const unsigned bx = (LG_NORM_REV & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     const double* p = partial + (long long)n * nchunk * 3;
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(256) void apply16p_kernel(const __bf16* __restrict_
       const double a = (double)gamma[0] / (sigma + (double)LG_IN_EPS);
       const float mu_hi = (float)mean;
       sst[0] = mu_hi; sst[1] = (float)sigma; sst[2] = (float)a; sst[3] = beta[0]; sst[4] = (float)(mean - (double)mu_hi);
-      if (blockIdx.x == 0) {
+      if (bx == 0) {
         float* o = stats + (long long)n * LG_NSTAT;
         o[0] = mu_hi; o[1] = (float)sigma; o[2] = (float)a; o[3] = beta[0];
         o[4] = (float)(mean - (double)mu_hi); o[5] = 0.f; o[6] = 0.f; o[7] = 0.f;
@@ -462,7 +472,10 @@ __global__ __launch_bounds__(256) void apply16p_kernel(const __bf16* __restrict_
   const float mu = sst[0], a = sst[2], b = sst[3], mul = sst[4];
   const long long base = (long long)n * L8;
   const unsigned stride = gridDim.x * blockDim.x * EW8_UNR;
-  for (unsigned i0 = blockIdx.x * blockDim.x * EW8_UNR + threadIdx.x; i0 < L8; i0 += stride) {
+  const int ntrip = (int)((L8 + stride - 1) / stride);
+  for (int tr = 0; tr < ntrip; ++tr) {
+    const unsigned i0 = (unsigned)((LG_NORM_REV & 1) ? ntrip - 1 - tr : tr) * stride + bx * blockDim.x * EW8_UNR + threadIdx.x;
+    if (i0 >= L8) continue;
     f32x8 v[EW8_UNR], sk[EW8_UNR];
 #pragma unroll
     for (int u = 0; u < EW8_UNR; ++u) {
@@ -552,10 +565,15 @@ __global__ __launch_bounds__(256) void bwd_apply16_kernel(const __bf16* __restri
   const unsigned tot = (unsigned)total8, l8 = (unsigned)L8;
   const unsigned ustep = DB ? gridDim.x * blockDim.x : 256u;                  // distance between a thread's units of one trip
   const unsigned stride = DB ? gridDim.x * blockDim.x * UNR : gridDim.x * blockDim.x * UNR;
-  const unsigned first = DB ? blockIdx.x * blockDim.x + threadIdx.x : blockIdx.x * blockDim.x * UNR + threadIdx.x;
+  const unsigned rb = (LG_NORM_REV & 2) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;   // (the block's data AND its column-sum row: results unchanged)
+  const unsigned first = DB ? rb * blockDim.x + threadIdx.x : rb * blockDim.x * UNR + threadIdx.x;
   f32x8 csum;
   csum.lo = f32x4{0.f, 0.f, 0.f, 0.f}; csum.hi = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (unsigned i0 = first; i0 < tot; i0 += stride) {
+  const int ntrip = (int)(((unsigned long long)tot + stride - 1) / stride);
+  for (int tr = 0; tr < ntrip; ++tr) {
+    const unsigned long long i0l = (unsigned long long)((LG_NORM_REV & 2) ? ntrip - 1 - tr : tr) * stride + first;
+    if (i0l >= tot) continue;
+    const unsigned i0 = (unsigned)i0l;
     f32x8 xs[UNR], gs[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -594,11 +612,11 @@ __global__ __launch_bounds__(256) void bwd_apply16_kernel(const __bf16* __restri
     __syncthreads();
     const int q = threadIdx.x;  // channel octet
     if (q < C8) {
-      const int base = (int)(((long long)blockIdx.x * 256) % C8);
+      const int base = (int)(((long long)rb * 256) % C8);
       f32x4 tl = {0.f, 0.f, 0.f, 0.f}, th = {0.f, 0.f, 0.f, 0.f};
       for (int k = (q - base + C8) % C8; k < 256; k += C8) { tl += sacc[2 * k]; th += sacc[2 * k + 1]; }
-      *reinterpret_cast<f32x4*>(colpart + ((long long)blockIdx.x * C8 + q) * 8) = tl;
-      *reinterpret_cast<f32x4*>(colpart + ((long long)blockIdx.x * C8 + q) * 8 + 4) = th;
+      *reinterpret_cast<f32x4*>(colpart + ((long long)rb * C8 + q) * 8) = tl;
+      *reinterpret_cast<f32x4*>(colpart + ((long long)rb * C8 + q) * 8 + 4) = th;
     }
   }
 }
