@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64) void stats_final_kernel(const double* __restric
 #ifndef LG_NORM_NT
 #define LG_NORM_NT 5
 #endif
-// The bf16 apply / backward-apply passes walk their maps from the END (bits: 1 apply16p, 2 bwd_apply16).  Their producers (the conv
+// The bf16 apply / backward-apply passes walk their maps from the END (bits: 1 apply16p, 2 bwd_apply16; 4 / 8 their fp32 twins).  Their producers (the conv
 // kernels) write a map front to back and their consumers read it front to back: a pass in between that starts at the END meets what the
 // producer wrote last — still in the Infinity Cache when the map is larger than it — and leaves the START of its own output for the
 // consumer's first reads.  Round 4, whole step, one box, three rounds: 10.79 / 10.76 / 10.72 ms (0) against 10.75 / 10.66 / 10.64 (3),
@@ -130,7 +130,12 @@ __global__ __launch_bounds__(256) void apply_kernel(const float* __restrict__ x,
   // EW_UNR independent 16-B loads per thread per trip: a single load in flight per thread leaves the pass latency-bound
   // (measured 2.5-3.9 TB/s against 5.5+ for a streaming copy)
   const unsigned stride = gridDim.x * blockDim.x * EW_UNR, tot = (unsigned)total4, l4 = (unsigned)L4;
-  for (unsigned i0 = blockIdx.x * blockDim.x * EW_UNR + threadIdx.x; i0 < tot; i0 += stride) {  // block-contiguous 16-KB trips
+  const unsigned rb = (LG_NORM_REV & 4) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  const int ntrip = (int)(((unsigned long long)tot + stride - 1) / stride);
+  for (int tr = 0; tr < ntrip; ++tr) {  // block-contiguous 16-KB trips (LG_NORM_REV & 4: from the end of the map)
+    const unsigned long long i0l = (unsigned long long)((LG_NORM_REV & 4) ? ntrip - 1 - tr : tr) * stride + rb * blockDim.x * EW_UNR + threadIdx.x;
+    if (i0l >= tot) continue;
+    const unsigned i0 = (unsigned)i0l;
     f32x4 v[EW_UNR], sk[EW_UNR];
 #pragma unroll
     for (int u = 0; u < EW_UNR; ++u) {
@@ -291,7 +296,12 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
   constexpr int UNR = DB ? 1 : EW_UNR;  // DB: a thread must stay on one channel quad -> plain grid stride
   const unsigned stride = gridDim.x * blockDim.x * UNR, tot = (unsigned)total4, l4 = (unsigned)L4;
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-  for (unsigned i0 = blockIdx.x * blockDim.x * UNR + threadIdx.x; i0 < tot; i0 += stride) {
+  const unsigned rb = (LG_NORM_REV & 8) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;   // (data and column-sum row alike)
+  const int ntrip = (int)(((unsigned long long)tot + stride - 1) / stride);
+  for (int tr = 0; tr < ntrip; ++tr) {
+   const unsigned long long i0l = (unsigned long long)((LG_NORM_REV & 8) ? ntrip - 1 - tr : tr) * stride + rb * blockDim.x * UNR + threadIdx.x;
+   if (i0l >= tot) continue;
+   const unsigned i0 = (unsigned)i0l;
    f32x4 xs[UNR], gs[UNR];
 #pragma unroll
    for (int u = 0; u < UNR; ++u) {
@@ -337,10 +347,10 @@ __global__ __launch_bounds__(256) void bwd_apply_kernel(const float* __restrict_
     __syncthreads();
     const int q = threadIdx.x;  // channel quad
     if (q < C4) {
-      const int base = (int)(((long long)blockIdx.x * 256) % C4);
+      const int base = (int)(((long long)rb * 256) % C4);
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
       for (int k = (q - base + C4) % C4; k < 256; k += C4) t += sacc[k];
-      *reinterpret_cast<f32x4*>(colpart + ((long long)blockIdx.x * C4 + q) * 4) = t;
+      *reinterpret_cast<f32x4*>(colpart + ((long long)rb * C4 + q) * 4) = t;
     }
   }
 }
