@@ -43,6 +43,16 @@ class GradSync:
             env = os.environ.get("LG_RESERVED_CUS")
             self.reserve_cus(int(env) if env not in (None, "") else RESERVED_CUS_DP)
 
+    def force_enable(self):
+        """Run the exchange even at world size 1 (a one-GPU box: librccl loads, the communicator is built, the side-stream / event
+        plumbing and the per-set waits are the real ones; an all-reduce over one rank leaves the gradients as they are)."""
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("GradSync.force_enable: no process group")
+        self.enabled = True
+        self.world_size = dist.get_world_size()
+        if self.on_gpu and self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(device=self.device)
+
     # ------------------------------------------------------------------ CU budget / rehearsal
     def reserve_cus(self, n: int):
         """Persistent kernels size their grids to (CUs - n) from now on (process-wide)."""
@@ -75,6 +85,8 @@ class GradSync:
     # ------------------------------------------------------------------ exchange
     def launch(self, name, store, start, end):
         """All-reduce(sum) store.grad[start:end]; non-blocking for the compute stream."""
+        if name in self._pending:   # a second launch would drop the first one's event / work handle (on gloo: a handle nobody waits for)
+            raise RuntimeError(f"GradSync.launch: the exchange of set {name!r} is still pending — wait({name!r}) first")
         if self._rehearsal is not None:
             from . import _lib
             n = (end - start) // 4 * 4

@@ -227,10 +227,21 @@ def instnorm(x, gamma, beta, eps=IN_EPS, xq=None):
     return y.reshape(x.shape), (c, sigma, s)
 
 
+# Scale of the two scalar gradients (sums with heavy cancellation): while a dict, instnorm_bwd appends per call
+# (sum |t|, sqrt(sum t^2)) of the summands t of dgamma and of dbeta under the current tag — step_gradients maps them to weight
+# indices (out["scalar_scale"]) so that a test can bound the error of such a sum against its summands, not its value.
+_SCALE_LOG = None
+_SCALE_TAG = None
+
+
 def instnorm_bwd(cache, gamma, dy):
     c, sigma, s = cache
     B = dy.shape[0]
     dyf = dy.reshape(B, -1)
+    if _SCALE_LOG is not None:
+        tg = dyf * c / s
+        _SCALE_LOG.setdefault(_SCALE_TAG, []).append(((float(np.abs(tg).sum()), float(np.sqrt((tg * tg).sum()))),
+                                                      (float(np.abs(dyf).sum()), float(np.sqrt((dyf * dyf).sum())))))
     m1 = dyf.mean(axis=1, keepdims=True)
     m2 = (dyf * c).mean(axis=1, keepdims=True)
     dx = (gamma / s) * (dyf - m1 - c * m2 / (s * sigma))
@@ -588,9 +599,41 @@ def step_gradients(cfg: Cfg, W, batch_no: int, inp: Dict[str, np.ndarray], fake_
     noise, new_image (the RNG-dependent step inputs are inputs: SURVEY.md a17).
     Returns dict with fake_image, adj_image, losses and the three FULL gradient lists
     (the trainer then keeps the subset chosen by train_weight_indices)."""
+    global _SCALE_LOG, _SCALE_TAG
     img1, c1, img2, c2 = inp["real_image_1"], inp["real_cond_1"], inp["real_image_2"], inp["real_cond_2"]
     noise, new_image = inp["noise"], inp["new_image"]
     out = {}
+    _SCALE_LOG, _SCALE_TAG = {}, "fwd"
+    try:
+        return _step_gradients(cfg, W, batch_no, inp, fake_override, adj_override, out, img1, c1, img2, c2, noise, new_image)
+    finally:
+        _SCALE_LOG = None
+
+
+def _scalar_scales(log):
+    """tag -> per-call ((l1, l2) of dgamma, (l1, l2) of dbeta), calls in level order 4, 3, 2, 1 (+ the dense norm last for G / A)
+    -> {model: {weight index: (l1, l2)}}; D's two passes add (the bound of a sum of two sums)."""
+    sc = {"D": {}, "G": {}, "A": {}}
+    for tag in ("D_real", "D_fake"):
+        for j, (g, b) in enumerate(log.get(tag, [])):
+            i = 3 - j
+            for idx, v in ((4 * i + 2, g), (4 * i + 3, b)):
+                o = sc["D"].get(idx, (0.0, 0.0))
+                sc["D"][idx] = (o[0] + v[0], math.hypot(o[1], v[1]))
+    recs = log.get("G", [])
+    for j, (g, b) in enumerate(recs[:4]):
+        i = 3 - j
+        sc["G"][4 + 4 * i + 2], sc["G"][4 + 4 * i + 3] = g, b
+    if len(recs) == 5:
+        sc["G"][2], sc["G"][3] = recs[4]
+    recs = log.get("A", [])
+    if len(recs) == 5:
+        sc["A"][2], sc["A"][3] = recs[4]
+    return sc
+
+
+def _step_gradients(cfg, W, batch_no, inp, fake_override, adj_override, out, img1, c1, img2, c2, noise, new_image):
+    global _SCALE_TAG
     fake, gcache = generator_fwd(cfg, W["G"], noise, c2)
     out["fake_image_own"] = fake
     if fake_override is not None:
@@ -603,15 +646,20 @@ def step_gradients(cfg: Cfg, W, batch_no: int, inp: Dict[str, np.ndarray], fake_
     # eager_trainer.py:93-96
     gen_loss = (bce_mean(soft(1.0), fake_pr) + bce_mean(c2, fake_c) + cfg.l1_lambda * l1_mean(img2, fake))
     # disc tape (eager_trainer.py:145)
+    _SCALE_TAG = "D_real"
     gr, _ = discriminator_bwd(cfg, W["D"], rcache, bce_mean_bwd(soft(1.0), real_pr),
                               2.0 * bce_mean_bwd(c1, real_c))
+    _SCALE_TAG = "D_fake"
     gf, _ = discriminator_bwd(cfg, W["D"], fcache, bce_mean_bwd(soft(0.0), fake_pr), np.zeros_like(fake_c))
+    _SCALE_TAG = "D_gen"
     dD = [a + b for a, b in zip(gr, gf)]
     # gen tape (eager_trainer.py:149)
     _, d_fake = discriminator_bwd(cfg, W["D"], fcache, bce_mean_bwd(soft(1.0), fake_pr),
                                   bce_mean_bwd(c2, fake_c), need_wgrad=False, need_input_grad=True)
     d_fake = d_fake + cfg.l1_lambda * l1_mean_bwd_b(img2, fake)
+    _SCALE_TAG = "G"
     dG = generator_bwd(cfg, W["G"], gcache, d_fake)
+    _SCALE_TAG = "A_disc"
     out.update(fake_image=fake, gen_loss=gen_loss, disc_loss=disc_loss, dD=dD, dG=dG,
                real_pr=real_pr, real_c=real_c, fake_pr=fake_pr, fake_c=fake_c,
                adj_image=None, adj_loss=None, dA=None)
@@ -631,7 +679,9 @@ def step_gradients(cfg: Cfg, W, batch_no: int, inp: Dict[str, np.ndarray], fake_
         _, d_adj = discriminator_bwd(cfg, W["D"], dcache, bce_mean_bwd(soft(1.0), adj_pr),
                                      bce_mean_bwd(adj_t_cond, adj_c), need_wgrad=False, need_input_grad=True)
         d_adj = d_adj + cfg.l1_lambda * l1_mean_bwd_b(adj_t_img, adj_img)
+        _SCALE_TAG = "A"
         out.update(adj_image=adj_img, adj_loss=adj_loss, dA=adjuster_bwd_own(cfg, W, acache, d_adj))
+    out["scalar_scale"] = _scalar_scales(_SCALE_LOG)
     return out
 
 

@@ -172,3 +172,47 @@ def test_train_loop_with_file_io_is_rank_safe(tmp_path):
     assert (tmp_path / "res" / "train" / "gen" / "2-4.jpg").is_file() and (tmp_path / "res" / "test" / "disc" / "1-6.json").is_file()
     state = torch.load(ck / "ckpt-2.pt", map_location="cpu", weights_only=True)
     assert state["input_step"] == 24   # 12 steps per epoch per rank (24 batches, 2 per step), two epochs: the Philox input stream position is saved
+
+
+def _rccl_single_worker(outdir):
+    """Fresh process (no GPU call before init_process_group): a world-size-1 `nccl` (= RCCL) group on cuda:0."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0), timeout=datetime.timedelta(seconds=120))
+    try:
+        cfg = O.Cfg(**CFG)
+        W = perturbed(cfg, 23)
+        tr_p, tr_s = build(cfg, W, "bf16"), build(cfg, W, "bf16")
+        assert not tr_p.sync.enabled
+        tr_s.sync.force_enable()
+        assert tr_s.sync.enabled and tr_s.sync.world_size == 1 and tr_s.sync.comm_stream is not None
+        for b in (10, 11, 12):   # a partition step, two full steps with the Adjuster branch
+            inp = dev_inputs(_inputs(cfg, 1, b))
+            rp = tr_p.train_step_from_inputs(b, inp)
+            rs = tr_s.train_step_from_inputs(b, inp)
+            torch.cuda.synchronize()
+            assert not tr_s.sync._pending
+            for x, y in zip(rp, rs):
+                assert (x is None) == (y is None) and (x is None or torch.equal(x, y)), b
+            for x, y in ((tr_p.store.flat, tr_s.store.flat), (tr_p.store.m, tr_s.store.m), (tr_p.store.v, tr_s.store.v), (tr_p.store.grad, tr_s.store.grad)):
+                assert torch.equal(x, y), b
+        loaded = [ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln or "libnccl" in ln]
+        with open(os.path.join(outdir, "rccl_ok.txt"), "w") as f:
+            f.write("\n".join(sorted(set(loaded))) or "none")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world_size_one_is_bit_identical(tmp_path):
+    """De-risks the first multi-GPU run on the one-GPU box: librccl loads, a communicator builds with
+    HSA_ENABLE_IPC_MODE_LEGACY=0, three steps run their three all-reduces per step on the side stream with the per-set waits in
+    front of each Adam, `destroy_process_group` returns — and every bit of weights, Adam slots, gradients and outputs equals the
+    plain step (an all-reduce over one rank is the identity, 1 / world = 1)."""
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_single_worker, args=(str(tmp_path),))
+    p.start()
+    _join_all([p], 300)
+    libs = (tmp_path / "rccl_ok.txt").read_text()
+    assert "rccl" in libs or "nccl" in libs, libs   # the collective library really is in the process

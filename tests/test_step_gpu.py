@@ -129,6 +129,10 @@ def check_grads(tr, ref, sets, tol, tag="", only=None):
                 continue
             d = got[:exp.size] - exp
             if exp.size == 1:
+                sc = (ref.get("scalar_scale") or {}).get(m, {}).get(i)
+                if os.environ.get("LG_SCALAR_REPORT"):
+                    print(f"SCALAR {tag} {m}[{i}] got {got[0]:.6e} exp {exp[0]:.6e} d {d[0]:.3e} gmax {gmax:.3e} d/gmax {abs(d[0]) / gmax:.3e}"
+                          + (f" l1 {sc[0]:.3e} l2 {sc[1]:.3e} d/l1 {abs(d[0]) / sc[0]:.3e} d/l2 {abs(d[0]) / sc[1]:.3e}" if sc else ""))
                 assert abs(d[0]) <= tol["grad_rms"] * abs(exp[0]) + tol["sfloor"] * gmax, (tag, m, i, d[0], exp[0], gmax)
             else:
                 rms = np.sqrt((d * d).mean()) / (np.sqrt((exp * exp).mean()) + 1e-30)
