@@ -294,12 +294,6 @@ int lg_grid_cus(void);
 /* one-GPU rehearsal of an all-reduce's CU footprint (bench.py --dp-contention): `workgroups` blocks of `threads` (256 | 512)
  * stream dst = 0.5 dst + src over n floats (n % 4 == 0), `passes` times — what a ring step does to the CUs it occupies */
 int lg_contention_probe(float* dst, const float* src, long long n, int workgroups, int threads, int passes, void* stream);
-/* one wave beside the step (launch it on a SIDE stream): shader clock held, in 1-ms windows, until *stop_flag != 0 (device
- * memory, raised by lg_clock_stop) or max_ms have passed — an exit the wave always reaches.  out5 = {sum d s_memtime,
- * sum d s_memrealtime (100 MHz ticks), min window kHz, max window kHz, number of windows}: mean clock = out5[0] / out5[1] x 100 MHz;
- * series (optional, series_cap entries): kHz per window */
-int lg_clock_probe(unsigned long long* out5, const int* stop_flag, long long max_ms, unsigned* series, int series_cap, void* stream);
-int lg_clock_stop(int* stop_flag, void* stream);
 /* in-kernel clock census: while buf3 (3 x 64-bit, device memory, zeroed by the caller) is registered, every block of the kernels that
  * support it (conv_down3: the step's dominant kernel) adds {d s_memtime, d s_memrealtime (100 MHz), 1} of its own life to it;
  * nullptr switches it off */

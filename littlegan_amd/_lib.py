@@ -97,8 +97,6 @@ SIGNATURES = {
     "lg_set_reserved_cus": (I, [I]),
     "lg_grid_cus": (I, []),
     "lg_contention_probe": (I, [P, P, L, I, I, I, P]),
-    "lg_clock_probe": (I, [P, P, L, P, I, P]),
-    "lg_clock_stop": (I, [P, P]),
     "lg_set_clock_census": (I, [P]),
     "lg_clock_sample": (I, [P, I, P]),
     "lg_augment_drawn": (I, [P, P, I, I, I, F, F, F, F, F, L, L, L, P, Z, P]),

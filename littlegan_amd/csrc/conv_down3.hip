@@ -87,7 +87,6 @@ struct D3Params {
   int stamp_lite;              // only the block's first / last stamp (the per-phase stamps cost ~11 % and change the clock)
 };
 
-__device__ __forceinline__ float lg_rfl(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
 __device__ __forceinline__ int pix32(int r) {  // MFMA row -> tile pixel inside its 32-pixel group (see conv_halo.hip)
   const int q = r >> 2, lo = r & 3;
   const int odd = (q ^ (q >> 1) ^ (q >> 2)) & 1;
@@ -120,10 +119,15 @@ constexpr int toff_bytes(int t) {  // tap t = ky*5+kx: LDS byte offset of its so
 // Measured in the C3 step (round 4, same box, A/B by LG_NO_BWDNORM): the N = 64 level (convT4's data gradient at 2B = 512: apply pass
 // 303 us + conv 321 us -> 552 us) gains 72 us per launch; the N = 128 level (convT3: 150 + 222 -> 395 us) LOSES 23 — 17 VALU
 // operations per element, 1.3 x the elements (halo), land on a kernel that was matrix-bound, not HBM-bound — and is not instantiated.
-// Two compiler facts from the way: (1) the staging arithmetic must be pinned behind the tap loop (see commit below); (2) the per-item
-// coefficient record must be read through the constant address space (lg_as_const, lg_common.h): as a plain load hipcc made it a
-// VECTOR load inside the item loop, `s_waitcnt vmcnt(0)` at every item boundary — and that build was NOT deterministic with two
-// blocks per CU (one block per CU: deterministic; tests/diagnostics/bwdnorm_det.py), which the scalar-load build is.
+// Two facts from the way: (1) the staging arithmetic must be pinned behind the tap loop (see commit below); (2) the per-item
+// coefficient record is read through the constant address space (lg_as_const, lg_common.h: as a plain load hipcc made it a VECTOR
+// load inside the item loop, `s_waitcnt vmcnt(0)` at every item boundary) AND every field is made wave-uniform explicitly
+// (lg_uniform), so that the staging arithmetic takes scalar operands.  The vector-load build (-DLG_D3_COEF_PLAIN reproduces it) was
+// NOT deterministic with two blocks per CU: hipcc kept the record as per-lane copies paired in 64-bit registers and formed g' - m1 as
+// a packed fp32 subtraction selecting the pair's HIGH register; read back through one-hot weights (tests/diagnostics/bwdnorm_probe.py)
+// every wrong operand element — 82 of 82 — was the LOW result of that instruction, bit-equal to the value with m1 not subtracted.
+// No wait, barrier or scheduling hole is involved (full waits in front of every instruction leave it in place); round-5 analysis in
+// DESIGN 11a.  tests/test_launch_shapes_gpu.py::test_persistent_kernels_are_deterministic launches this form at B = 512.
 template <bool STATS, bool FUSE = false, bool PAIR = false, int NW = 128, int NORM = 0>
 __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   static_assert(!(STATS && FUSE), "forward moments and backward sums are never needed together");
@@ -219,38 +223,22 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   unsigned hoff[PPT];
   float nmu0 = 0.f, nml0 = 0.f, nna0 = 0.f, nnb0 = 0.f;   // NORM: the item's sample
   LgBwdCoef bco{};                                         // BWDNORM: the item's sample
-  int chk_n = 0, chk_c0 = 0, chk_in = 0, chk_item = 0; (void)chk_n; (void)chk_c0; (void)chk_in; (void)chk_item;   // diagnostic builds (LG_D3_COEFCHK / LG_D3_DZDUMP)
   auto set_item = [&](const Item& it) __attribute__((always_inline)) {
     if constexpr (NORM == 1) {
       const lg_const_f32p sp = lg_as_const(p.nstats + (long long)it.n * 8);   // uniform + constant space: scalar loads
-      nmu0 = sp[0]; nna0 = sp[2]; nnb0 = sp[3]; nml0 = sp[4];
+      nmu0 = lg_uniform(sp[0]); nna0 = lg_uniform(sp[2]); nnb0 = lg_uniform(sp[3]); nml0 = lg_uniform(sp[4]);   // SGPRs whatever the load (lg_common.h)
     }
     if constexpr (NORM == 2) {
 #ifdef LG_D3_COEF_PLAIN   // diagnostic build: the round-4 form whose BWDNORM instantiation was not deterministic
       const float* sp = p.bcoef + (long long)it.n * 8;
-      chk_n = it.n;
 #else
       const lg_const_f32p sp = lg_as_const(p.bcoef + (long long)it.n * 8);    // uniform + constant space: one 32-byte scalar load
 #endif
+#ifdef LG_D3_COEF_PLAIN
       bco.mu = sp[0]; bco.mul = sp[1]; bco.a = sp[2]; bco.b = sp[3]; bco.m1 = sp[4]; bco.m2 = sp[5]; bco.m1l = sp[6]; bco.m2l = sp[7];
-#ifdef LG_D3_COEF_DELAY   // diagnostic: the record's registers are pinned here (the compiler waits for the loads in front of this) and the wave idles ~256 cycles before anything copies them
-      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
-                   : "+v"(bco.mu), "+v"(bco.mul), "+v"(bco.a), "+v"(bco.b), "+v"(bco.m1), "+v"(bco.m2), "+v"(bco.m1l), "+v"(bco.m2l));
-#endif
-#ifdef LG_D3_COEF_PIN     // diagnostic: the same pin WITHOUT the idle cycles (LG_D3_COEF_PIN = number of s_nop 0 behind the compiler's wait: 0, 1, 4, 16)
-#define LG_STR2(x) #x
-#define LG_STR(x) LG_STR2(x)
-      asm volatile(".rept " LG_STR(LG_D3_COEF_PIN) "\n\ts_nop 0\n\t.endr"
-                   : "+v"(bco.mu), "+v"(bco.mul), "+v"(bco.a), "+v"(bco.b), "+v"(bco.m1), "+v"(bco.m2), "+v"(bco.m1l), "+v"(bco.m2l));
-#endif
-#ifdef LG_D3_COEF_VMOV    // diagnostic (WITHOUT LG_D3_COEF_PLAIN): scalar loads, then per-lane copies in VGPRs — VGPR operands of the staging arithmetic without any vector load
-      asm volatile("v_mov_b32 %0, %8\n\tv_mov_b32 %1, %9\n\tv_mov_b32 %2, %10\n\tv_mov_b32 %3, %11\n\tv_mov_b32 %4, %12\n\tv_mov_b32 %5, %13\n\tv_mov_b32 %6, %14\n\tv_mov_b32 %7, %15"
-                   : "=v"(bco.mu), "=v"(bco.mul), "=v"(bco.a), "=v"(bco.b), "=v"(bco.m1), "=v"(bco.m2), "=v"(bco.m1l), "=v"(bco.m2l)
-                   : "s"(sp[0]), "s"(sp[1]), "s"(sp[2]), "s"(sp[3]), "s"(sp[4]), "s"(sp[5]), "s"(sp[6]), "s"(sp[7]));
-#endif
-#ifdef LG_D3_COEF_RFL   // diagnostic: the vector-loaded record made uniform again (lane 0's copy)
-      bco.mu = lg_rfl(bco.mu); bco.mul = lg_rfl(bco.mul); bco.a = lg_rfl(bco.a); bco.b = lg_rfl(bco.b);
-      bco.m1 = lg_rfl(bco.m1); bco.m2 = lg_rfl(bco.m2); bco.m1l = lg_rfl(bco.m1l); bco.m2l = lg_rfl(bco.m2l);
+#else   // explicitly wave-uniform: the staging arithmetic takes SCALAR operands whatever load the compiler emits (lg_common.h)
+      bco.mu = lg_uniform(sp[0]); bco.mul = lg_uniform(sp[1]); bco.a = lg_uniform(sp[2]); bco.b = lg_uniform(sp[3]);
+      bco.m1 = lg_uniform(sp[4]); bco.m2 = lg_uniform(sp[5]); bco.m1l = lg_uniform(sp[6]); bco.m2l = lg_uniform(sp[7]);
 #endif
     }
 #pragma unroll
@@ -262,10 +250,6 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
     }
   };
   auto issue = [&](const Item& it, int c0, u32x4 (&v)[PPT]) __attribute__((always_inline)) {
-    chk_in = it.n; chk_c0 = c0;
-#ifdef LG_D3_DZDUMP
-    chk_item = (it.n * p.tpi + (it.y0 / TH) * p.tpi_x + it.x0 / TW);
-#endif
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16*>(p.src + (long long)it.n * sample_elems), 0, (PAIR ? 2 : 1) * sample_elems * 2, 0x00027000);
 #pragma unroll
@@ -285,35 +269,6 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
     for (int u = 0; u < PPT; ++u)
       if (pl[u] >= 0) {
         u32x4 w = v[u];
-#ifdef LG_D3_COEFCHK
-        if constexpr (NORM == 2) {   // diagnostic: are the registers the staging arithmetic is about to use what memory holds?
-          if (p.stamps) {
-            const volatile float* sp2 = p.bcoef + (long long)chk_n * 8;
-            const float f2[8] = {sp2[0], sp2[1], sp2[2], sp2[3], sp2[4], sp2[5], sp2[6], sp2[7]};
-            const float f1[8] = {bco.mu, bco.mul, bco.a, bco.b, bco.m1, bco.m2, bco.m1l, bco.m2l};
-            unsigned bad = 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) bad |= (__builtin_bit_cast(unsigned, f1[i]) != __builtin_bit_cast(unsigned, f2[i])) << i;
-            const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.src + (long long)chk_in * sample_elems), 0, sample_elems * 2, 0x00027000);
-            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.gsrc + (long long)chk_in * sample_elems), 0, sample_elems * 2, 0x00027000);
-            const u32x4 z2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, hoff[u] + (unsigned)(chk_c0 * 2), 0, 1));
-            const u32x4 g2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, hoff[u] + (unsigned)(chk_c0 * 2), 0, 1));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { bad |= (z2[i] != w[i]) << 8; bad |= (g2[i] != gv[u][i]) << 9; }
-            bad |= (chk_n != chk_in) << 10;
-            if (bad) {
-              const unsigned long long ix = atomicAdd(p.stamps, 1ull);
-              if (ix < 8000) {
-                unsigned long long* r = p.stamps + 8 + ix * 4;
-                r[0] = ((unsigned long long)blockIdx.x << 32) | ((unsigned)tid << 16) | ((unsigned)u << 12) | bad;
-                r[1] = ((unsigned long long)(unsigned)chk_n << 32) | ((unsigned)chk_in << 16) | (unsigned)chk_c0;
-                r[2] = ((unsigned long long)__builtin_bit_cast(unsigned, f1[0]) << 32) | __builtin_bit_cast(unsigned, f2[0]);
-                r[3] = ((unsigned long long)__builtin_bit_cast(unsigned, f1[4]) << 32) | __builtin_bit_cast(unsigned, f2[4]);
-              }
-            }
-          }
-        }
-#endif
         if constexpr (NORM == 2) {   // out-of-range pieces: z = g = 0 came back, but dz(0, 0) != 0 — the padding of dz is zero
           const u32x4 dn = lg_bwdnorm8(w, gv[u], bco, p.nalpha);
           const bool inside = hoff[u] != OOB;
@@ -339,14 +294,6 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
           }
         }
         *reinterpret_cast<u32x4*>(buf + pl[u]) = w;
-#ifdef LG_D3_DZDUMP   // diagnostic: the operand piece as staged, [item][slice][piece q = tid + 256 u] x 16 B (+ the record it was formed with, once per thread)
-        if constexpr (NORM == 2) {
-          if (p.stamps) {
-            u32x4* d = reinterpret_cast<u32x4*>(p.stamps) + ((long long)chk_item * nchunk + chk_c0 / KC) * (PPT * 256) + tid + u * 256;
-            __builtin_nontemporal_store(w, d);
-          }
-        }
-#endif
       }
   };
   // weight fragment of (tap t, column tile tn, k-step kb) for this wave's 32 columns
@@ -475,12 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
     // NORM forms: the staging arithmetic stays BEHIND the tap loop.  Left free, hipcc hoists its first unpacking shifts into the first
     // taps of the slice, and with them an `s_waitcnt vmcnt(2)` for the halo pieces requested a few instructions earlier: every slice
     // then opens by sitting out the HBM latency of its own prefetch (seen in the .s of the BWDNORM form, round 4).
-#ifndef LG_D3_NO_COMMIT_PIN
     if constexpr (NORM != 0) __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef LG_D3_COMMIT_WAITALL   // diagnostic: every load of the wave has landed before the staging arithmetic starts
-    if constexpr (NORM == 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#endif
     commit(smem + ((s + 1) & 1) * HB, hv);
     __syncthreads();  // slice s consumed by every wave, slice s+1 complete
     D3_STAMP();   // barrier passed
@@ -561,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
         if constexpr (FUSE) {
           // PAIR: the tile column of a thread's pieces is fixed ((tid >> 4) & 15): waves 0, 1 sweep sample n, waves 2, 3 n + 1
           const lg_const_f32p sp = lg_as_const(p.nf.stats + (long long)(cur.n + (PAIR ? wid >> 1 : 0)) * 8);   // scalar loads (lg_common.h)
-          lg_nf_accum(v, zq[q8], sp[0], sp[4], sp[2], sp[3], p.nf.alpha, nf1, nf2);
+          lg_nf_accum(v, zq[q8], lg_uniform(sp[0]), lg_uniform(sp[4]), lg_uniform(sp[2]), lg_uniform(sp[3]), p.nf.alpha, nf1, nf2);
         }
       }
       if constexpr (FUSE) {
@@ -721,10 +663,7 @@ static int down3_launch(const void* src16, const void* wpack, const float* bias,
   p.nstats = nstats; p.nalpha = nalpha;
   p.gsrc = (const __bf16*)g16; p.bcoef = bcoef;
   p.clk = lg_clock_census();
-#if defined(LG_D3_COEFCHK) || defined(LG_D3_DZDUMP)
-  { const char* e = getenv("LG_D3_DBGBUF"); p.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
-#endif
-  p.lds_order = lg_env_flag("LG_D3_LDS_ORDER") ? 1 : 0;
+  { static int lo = -1; if (lo < 0) lo = lg_env_flag("LG_D3_LDS_ORDER") ? 1 : 0; p.lds_order = lo; }   // (cached per call site)
   static int bpc = 0;   // resident blocks per CU
   if (!bpc) {
     bpc = 2;

@@ -84,6 +84,7 @@ struct U3Params {
   int B, Hs, Ws, tpi_x, tpi, nitems;
   LgNormFuse nf;       // FUSE instantiation: norm-backward sums of the produced gradient (lg_common.h)
   unsigned long long* stamps;  // diagnostic build (LG_U3_STAMPS): [block][8 waves][32]
+  int rotoff;          // 4-wave form: class-rotation offset of the SECOND workgroup of a CU (see ROT below)
 };
 
 __device__ __forceinline__ int pix32(int r) {
@@ -116,8 +117,15 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
   const int slot = C::WN == 2 ? (wid >> 1) : (wid & 3);
   const int cls_fixed = C::WN == 2 ? (slot == 0 ? 3 : slot == 1 ? 1 : slot == 2 ? 0 : 2)
                                    : (tsel == 0 ? (slot == 0 ? 3 : slot == 1 ? 1 : slot == 2 ? 2 : 0) : (slot == 0 ? 0 : slot == 1 ? 2 : slot == 2 ? 1 : 3));
-  int cls = C::ROT ? rot_class(wid) : cls_fixed;   // ROT: class of step s = rot_class(wid + s)
   const int G = gridDim.x;
+  // ROT: class of step s = rot_class(wid + s + rsh).  The two workgroups of a CU put one wave each on every SIMD and run the same
+  // program from the same start: in phase, a SIMD holds two 9-tap waves while another holds two 4-tap ones (18 : 8 taps).  The
+  // second workgroup of a CU (the upper half of the grid) can start its rotation rsh places on (LG_U3_ROTOFF; 2: its wave w runs the class
+  // that COMPLEMENTS the first workgroup's — (3, 0), (1, 2), (0, 3), (2, 1): 13 / 12 taps per SIMD and step).  Measured in round 5
+  // (scripts/probe/u3_rotoff_ab.sh, convT4 forward at B = 256): 145.3 / 143.1 us in phase, 141.4 (offset 1), 142.7 / 143.8 (offset 2) —
+  // the matrix pipe's balance is not what bounds this layer; default 0.
+  const int rsh = (C::ROT && (int)blockIdx.x >= (G + 1) / 2) ? p.rotoff : 0;
+  int cls = C::ROT ? rot_class(wid + rsh) : cls_fixed;
   const int lb = lg_xcd_remap(blockIdx.x, G);
   const int nsteps_all = (p.nitems + C::NT - 1) / C::NT;       // steps (NT tiles each) over the whole problem
   const int nmine = (nsteps_all - lb + G - 1) / G;
@@ -497,7 +505,7 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
     }
     (void)live;
     U3_STAMP();  // rows out
-    if constexpr (C::ROT) cls = rot_class(wid + s + 1);
+    if constexpr (C::ROT) cls = rot_class(wid + rsh + s + 1);
     if constexpr (!DEFER) __syncthreads();  // next halo complete, staging area free again
   }
   if constexpr (DEFER) {  // the last tile's rows
@@ -561,6 +569,7 @@ extern "C" int lg_conv_up3_nf_try(const void* src16, const void* wpack_up, const
   // with two tiles per step)
   static int t4_8w = -1;
   if (t4_8w < 0) t4_8w = lg_env_flag("LG_U3_T4_8W") ? 1 : 0;
+  { static int ro = -1; if (ro < 0) { const char* e = getenv("LG_U3_ROTOFF"); ro = e ? (atoi(e) & 3) : 0; } p.rotoff = ro; }   // A/B (round 5, measured: 141 - 145 us for offsets 0 / 1 / 2 — no effect, default 0)
   // the norm-backward sums are produced by the one-tile-per-step forms only: with two tiles per step a thread's row sweep covers
   // both tiles, i.e. possibly two samples, and the per-thread sums would mix them (no layer of the step asks for that form)
   const bool fuse = (Cs == 128 || !t4_8w) && nf && nf->z && nf->stats && nf->part && nparts_out && (size_t)B * p.tpi * 2 * sizeof(double) <= nf_bytes;

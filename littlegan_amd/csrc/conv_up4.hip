@@ -289,7 +289,7 @@ __device__ __forceinline__ void up4_run(const U4Params& p, char* smem, int lb, i
         if constexpr (FUSE) {
           // PAIR: the tile column of a thread's pieces is fixed ((tid >> 4) & 15): waves 0, 1 sweep sample n, waves 2, 3 n + 1
           const lg_const_f32p sp = lg_as_const(p.nf.stats + (long long)(cur.n + (PAIR ? wid >> 1 : 0)) * 8);   // scalar loads (lg_common.h)
-          lg_nf_accum(v, zq[q8], sp[0], sp[4], sp[2], sp[3], p.nf.alpha, nf1, nf2);
+          lg_nf_accum(v, zq[q8], lg_uniform(sp[0]), lg_uniform(sp[4]), lg_uniform(sp[2]), lg_uniform(sp[3]), p.nf.alpha, nf1, nf2);   // (cur.n, wid: wave-uniform)
         }
       }
       if constexpr (FUSE) {

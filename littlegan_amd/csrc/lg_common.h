@@ -155,6 +155,15 @@ __device__ __forceinline__ u32x4 lg_norm8(const u32x4 z8, float mu, float mul, f
 // weight-fragment ring (seen in the .s of conv_down3's normalising forms, round 4).  From the constant space it is an s_load.
 typedef const float __attribute__((address_space(4)))* lg_const_f32p;
 __device__ __forceinline__ lg_const_f32p lg_as_const(const float* p) { return (lg_const_f32p)(p); }
+// ... and every field of such a record is made wave-uniform EXPLICITLY (v_readfirstlane; folds away behind an s_load): the record then
+// lives in SGPRs whatever load the compiler chose, and the arithmetic that consumes it takes scalar operands.  Round 5: with
+// the record as per-lane VGPR copies (the vector-load build of conv_down3's BWDNORM form) hipcc paired the fields in 64-bit registers and
+// formed `g' - m1` as a PACKED fp32 subtraction that selects the pair's high register for both results; on gfx950 with a second wave on
+// the SIMD the LOW result of that instruction intermittently came out WITHOUT the subtraction (82 of 82 wrong operand elements read back
+// through one-hot weights: an even element, bit-equal to the value with m1 not subtracted) — launch-to-launch different outputs.  The
+// builds with scalar operands (s_load or readfirstlane), with the fields in the LOW registers of their pairs, or without packed fp32
+// instructions never showed it; memory ordering is not involved (full waits in front of every instruction leave it in place).
+__device__ __forceinline__ float lg_uniform(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
 
 // 8 bf16 z, 8 bf16 g -> 8 bf16 dz of the InstanceNorm + LeakyReLU backward, exactly bwd_apply16_kernel (norm.hip) in its
 // post-LeakyReLU form: c = (z - mu) - mul; g' = (a c + b > 0) ? g : alpha g; dz = a ((((g' - m1) - m1l) - c m2) - c m2l); RNE.

@@ -476,8 +476,10 @@ extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void
   hipStream_t st = (hipStream_t)stream;
   static int th8 = -1;
   if (th8 < 0) th8 = lg_env_flag("LG_N3W_TH8") ? 1 : 0;   // A/B switch
-  const bool th16 = Cs == 32 && s == 1 && H % 16 == 0 && small16 && !lg_env_flag("LG_N3W_F32") && !th8;   // 16-row tiles (bf16 path, final layer)
-  const bool p16 = small16 && !lg_env_flag("LG_N3W_F32");
+  static int n3w_f32 = -1;
+  if (n3w_f32 < 0) n3w_f32 = lg_env_flag("LG_N3W_F32") ? 1 : 0;   // (cached per call site: the table lookup takes a mutex)
+  const bool th16 = Cs == 32 && s == 1 && H % 16 == 0 && small16 && !n3w_f32 && !th8;   // 16-row tiles (bf16 path, final layer)
+  const bool p16 = small16 && !n3w_f32;
   const int ntiles = B * (H / (th16 ? 16 : 8)) * (W / 16), nblk = wgrad_blocks(ntiles, Cs, !p16);   // (the workspace is sized for the larger grid)
   const size_t lds = (size_t)(128 * Cs + (s * 8 + 4) * (s * 16 + 4) * 3 + 4) * 4;
   const __bf16* s16 = (const __bf16*)small16;
@@ -488,7 +490,7 @@ extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void
     a = true;
   }
   float* slab = (float*)workspace;
-  if (s16 && !lg_env_flag("LG_N3W_F32")) {  // bf16 path: bf16 MFMA straight from the mirror
+  if (s16 && !n3w_f32) {  // bf16 path: bf16 MFMA straight from the mirror
     // LDS: the wide operand's tile (also the merge buffer) + the bf16 RGBx halo of the 3-channel operand and its zero region
     auto ldsz = [&](int cs, int th = 8) {
       const size_t sb = (size_t)th * 16 * (cs * 2 + 16), mg = (size_t)75 * cs * 4;
@@ -507,7 +509,7 @@ extern "C" int lg_n3_wgrad_try(const float* big3, const float* small, const void
     else hipLaunchKernelGGL((n3_wgrad_kernel<2, false>), dim3(nblk), dim3(256), lds, st, big3, small, s16, slab, B, H, W, s, pad);
   }
   LG_CHECK_LAUNCH("lg_n3_wgrad");
-  lg_note_kernel((s16 && !lg_env_flag("LG_N3W_F32")) ? (th16 ? "n3_wgrad16_kernel<1,16>" : Cs == 32 ? "n3_wgrad16_kernel<1>" : "n3_wgrad16_kernel<2>") : "n3_wgrad_kernel<f32>");
+  lg_note_kernel((s16 && !n3w_f32) ? (th16 ? "n3_wgrad16_kernel<1,16>" : Cs == 32 ? "n3_wgrad16_kernel<1>" : "n3_wgrad16_kernel<2>") : "n3_wgrad_kernel<f32>");
   const int n = 75 * Cs;
   hipLaunchKernelGGL(n3_slab_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, st, (const float*)workspace, dw, nblk, n,
                      accumulate);

@@ -5,9 +5,7 @@
 //     serial tail of one block life.  Persistent launchers size their grids to lg_grid_cus() = CUs - reserved.
 //   * lg_contention_probe: the one-GPU rehearsal of that situation (bench.py --dp-contention K): K workgroups that stream
 //     read-add-write over a gradient-sized range, i.e. what one RCCL ring step does to the CUs it occupies.
-//   * lg_clock_probe: one wave that sits beside the step on a side stream and measures the shader clock the chip HOLDS
-//     (d s_memtime / d s_memrealtime x 100 MHz, MI355X_MICROARCH.md "DVFS give-back" item 6) in 1-ms windows until a flag in
-//     device memory is raised or its tick budget is spent — an exit condition the wave always reaches.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
@@ -50,8 +48,12 @@ extern "C" int lg_env_flag(const char* name) {
   for (int i = 0; i < n; ++i)
     if (slots[i].name == name || strcmp(slots[i].name, name) == 0) return slots[i].val;
   const char* e = getenv(name);
-  const int v = (e && *e) ? 1 : 0;
-  if (n < 64) { slots[n].name = name; slots[n].val = v; ++n; }
+  const int v = (e && *e) ? 1 : 0;   // set AND non-empty (round 4; `LG_NO_X=` no longer switches anything)
+  if (n >= 64) {   // a full table would silently re-read the environment on every call: the "read once" promise would be gone
+    fprintf(stderr, "littlegan_hip: lg_env_flag table full (64 switches) at %s — enlarge it\n", name);
+    abort();
+  }
+  slots[n].name = name; slots[n].val = v; ++n;
   return v;
 }
 
@@ -68,40 +70,6 @@ __global__ __launch_bounds__(512) void contention_kernel(float* __restrict__ dst
       d = d * 0.5f + a;
       reinterpret_cast<f32x4*>(dst)[i] = d;
     }
-}
-
-__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* __restrict__ out, const int* stop,
-                                                         unsigned long long max_ticks, unsigned window_ticks,
-                                                         unsigned* __restrict__ series, int series_cap) {
-  // one wave; lane 0 writes.  out: [0] d memtime, [1] d realtime (100 MHz), [2] min window kHz, [3] max window kHz, [4] windows;
-  // series[w] (optional) = kHz of window w, so that the caller can cut the windows that overlap ITS load out of the whole run.
-  // A window in which the cycle counter does not advance monotonically (seen once per run on this chip) is dropped.
-  const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime(), t_begin = __builtin_amdgcn_s_memtime();
-  unsigned long long r0 = r_begin, t0 = t_begin, lo = ~0ull, hi = 0, nwin = 0, tsum = 0, rsum = 0;
-  for (;;) {
-    __builtin_amdgcn_s_sleep(64);
-    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-    if (r1 - r0 >= window_ticks) {
-      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-      if (t1 > t0 && t1 - t0 < (r1 - r0) * 64ull) {   // < 6.4 GHz: a sane window
-        const unsigned long long khz = (t1 - t0) * 100000ull / (r1 - r0);   // cycles per 10-ns tick x 1e5 = kHz
-        lo = khz < lo ? khz : lo;
-        hi = khz > hi ? khz : hi;
-        tsum += t1 - t0; rsum += r1 - r0;
-        if (series && nwin < (unsigned long long)series_cap && threadIdx.x == 0) series[nwin] = (unsigned)khz;
-        ++nwin;
-      }
-      r0 = r1; t0 = t1;
-      if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || r1 - r_begin >= max_ticks) break;
-    }
-  }
-  if (threadIdx.x == 0) {
-    out[0] = tsum; out[1] = rsum; out[2] = lo; out[3] = hi; out[4] = nwin;
-  }
-}
-
-__global__ void clock_stop_kernel(int* flag) {   // a store the resident probe wave's system-scope poll sees (no cached copy in an L2)
-  if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // One wave that spins for `spin_ticks` of the 100 MHz clock and reports d s_memtime / d s_memrealtime: launched on the COMPUTE
@@ -131,16 +99,6 @@ extern "C" int lg_contention_probe(float* dst, const float* src, long long n, in
   return LG_OK;
 }
 
-extern "C" int lg_clock_probe(unsigned long long* out5, const int* stop_flag, long long max_ms, unsigned* series, int series_cap,
-                              void* stream) {
-  LG_CHECK_ARG(out5 && stop_flag && max_ms > 0 && max_ms <= 60000, "lg_clock_probe: bad args (max_ms in 1..60000)");
-  LG_CHECK_ARG(series_cap >= 0 && (series || series_cap == 0), "lg_clock_probe: series buffer / capacity mismatch");
-  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out5, stop_flag,
-                     (unsigned long long)max_ms * 100000ull, 100000u, series, series_cap);
-  LG_CHECK_LAUNCH("lg_clock_probe");
-  return LG_OK;
-}
-
 extern "C" int lg_clock_sample(unsigned long long* out3, int spin_us, void* stream) {
   LG_CHECK_ARG(out3 && spin_us > 0 && spin_us <= 1000, "lg_clock_sample: bad args (spin_us in 1..1000)");
   hipLaunchKernelGGL(clock_sample_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out3, (unsigned)spin_us * 100u);
@@ -148,17 +106,11 @@ extern "C" int lg_clock_sample(unsigned long long* out3, int spin_us, void* stre
   return LG_OK;
 }
 
-extern "C" int lg_clock_stop(int* stop_flag, void* stream) {
-  LG_CHECK_ARG(stop_flag, "lg_clock_stop: null flag");
-  hipLaunchKernelGGL(clock_stop_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stop_flag);
-  LG_CHECK_LAUNCH("lg_clock_stop");
-  return LG_OK;
-}
-
 // In-kernel clock census (bench.py's `clock` field): while a buffer is registered, every block of the persistent conv kernels that
 // support it (conv_down3.hip: the dominant kernel of the step) adds, at its end, {d s_memtime, d s_memrealtime, 1} of its own life to
-// buf3 — sum[0] / sum[1] x 100 MHz is the shader clock those blocks saw WHILE THEY RAN in the real step.  (A probe wave that sits
-// beside the step on a side stream does not see it: measured in round 4, it reads 2.39 GHz whatever the other CUs do, while a
-// sampling wave right behind back-to-back convs reads 2.14.)  nullptr = off (the default; two scalar instructions per block remain).
+// buf3 — sum[0] / sum[1] x 100 MHz is the shader clock those blocks saw WHILE THEY RAN in the real step.  (Round 4 also had a probe wave
+// resident on a side stream, lg_clock_probe; its one cross-check was invalid — device-wide synchronisations in the load loop waited for
+// the resident wave, so 99.5 % of its windows saw an idle chip — and it was removed in round 5.)  nullptr = off (the default; two scalar
+// instructions per block remain).
 extern "C" int lg_set_clock_census(unsigned long long* buf3) { g_clock_census = buf3; return LG_OK; }
 extern "C" unsigned long long* lg_clock_census(void) { return g_clock_census; }

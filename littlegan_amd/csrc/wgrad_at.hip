@@ -253,7 +253,11 @@ __global__ __launch_bounds__(512) void wgrad_at_kernel(const WgAtParams p) {
   }
 }
 
-inline int at_cus() { return lg_grid_cus(); }   // CUs the persistent grid may fill (runtime.hip)
+extern "C" int lg_device_cus(void);
+// The split-K plan — and with it the fp32 summation order of dW — is a function of the DEVICE, not of the CU reservation (lg_set_reserved_cus):
+// weight gradients stay bit-reproducible across reservation settings and across hipGraphs captured before a reservation changed.  With CUs
+// reserved the grid is a few blocks larger than the free CUs: a short tail, not a different result.
+inline int at_cus() { return lg_device_cus(); }
 
 // 0: not applicable, else the strip width (32 or 16)
 inline int at_shape(int Hm, int Wm, int cb, int cs) {

@@ -187,7 +187,8 @@ __global__ __launch_bounds__(512) void wgrad_at32_kernel(const Wg32Params p) {
   }
 }
 
-inline int at32_cus() { return lg_grid_cus(); }   // CUs the persistent grid may fill (runtime.hip)
+extern "C" int lg_device_cus(void);
+inline int at32_cus() { return lg_device_cus(); }   // the split plan (= summation order) depends on the device alone, see wgrad_at.hip
 
 // 0: not applicable, else the strip width (16: 16 x 4 strips; 8: whole 8-column maps, 8 rows)
 inline int at32_shape(int Hm, int Wm, int cb, int cs) {

@@ -1,8 +1,13 @@
+# Round 5: the non-deterministic BWDNORM build reproduced and read back.  Builds the reproducer variant of conv_down3.hip
+# (per-item record by vector load, -DLG_D3_COEF_PLAIN) beside the product library and runs, on a GPU box: the launch-to-launch pattern
+# (two and one block per CU), the one-hot-weight probe that reads the staged operand back, and the same two on the product library.
 set -x
-cd /root/repo && mkdir -p gpurun_out/r5a
-for v in d3plain d3plainnp ""; do
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out/bwdnorm
+[ -f littlegan_amd/liblittlegan_hip_d3plain.so ] || LG_EXTRA_FLAGS="-DLG_D3_COEF_PLAIN" LG_VARIANT_SOURCES=conv_down3.hip python -m littlegan_amd.csrc.build --variant d3plain
+for v in d3plain ""; do
   for bpc in 2 1; do
-    LG_LIB_VARIANT=$v LG_D3_BLOCKS_PER_CU=$bpc timeout -k 10 120 python tests/diagnostics/bwdnorm_pattern.py > gpurun_out/r5a/pattern_${v:-product}_bpc$bpc.log 2>&1 || echo "FAILED $v $bpc"
+    LG_LIB_VARIANT=$v LG_D3_BLOCKS_PER_CU=$bpc timeout -k 10 200 python tests/diagnostics/bwdnorm_pattern.py > gpurun_out/bwdnorm/pattern_${v:-product}_bpc$bpc.log 2>&1 || echo "FAILED $v $bpc"
   done
+  LG_LIB_VARIANT=$v LG_REPS=4 timeout -k 10 300 python tests/diagnostics/bwdnorm_probe.py > gpurun_out/bwdnorm/probe_${v:-product}.log 2>&1 || echo "FAILED probe $v"
 done
-LG_LIB_VARIANT=d3plain LG_B=64 timeout -k 10 120 python tests/diagnostics/bwdnorm_pattern.py > gpurun_out/r5a/pattern_d3plain_B64.log 2>&1 || echo FAILED B64
+grep -c "differing elements [1-9]" gpurun_out/bwdnorm/pattern_*.log; grep -h "^weights" gpurun_out/bwdnorm/probe_*.log | sort | uniq -c | sort -rn | head

@@ -39,10 +39,6 @@ tpi = tpx * tpy
 nitems = B * tpi
 bpc = int(os.environ.get("LG_D3_BLOCKS_PER_CU", "2"))
 G = min(nitems, bpc * 256)
-dbg = None
-if os.environ.get("LG_CHK"):   # LG_D3_COEFCHK build: the kernel reports staging registers that differ from what memory holds
-    dbg = torch.zeros(8 + 8000 * 4, dtype=torch.int64, device="cuda")
-    os.environ["LG_D3_DBGBUF"] = hex(dbg.data_ptr())
 outs = []
 for rep in range(REPS):
     o, pp = ops.convT_s2_dgrad_bn(z16, g16, coef, ALPHA, pack, cs, fuse=(zl16, stl, ALPHA))
@@ -81,19 +77,3 @@ for rep, (o, pb) in enumerate(outs):
     describe(o, f"launch {rep} vs apply+conv")
     print(f"   fused sums equal to the reference's: {bool(torch.equal(pb, pref))};  equal to launch 0: {bool(torch.equal(o, outs[0][0]))}")
 
-if dbg is not None:
-    import struct
-    d = dbg.cpu().numpy().astype("uint64")
-    n = int(d[0])
-    print(f"in-kernel check: {n} mismatching (thread, piece) records over {REPS} launches")
-    from collections import Counter
-    cb, cl, cu = Counter(), Counter(), Counter()
-    for i in range(min(n, 8000)):
-        r = [int(x) for x in d[8 + 4 * i: 12 + 4 * i]]
-        blk, tid, u, bad = r[0] >> 32, (r[0] >> 16) & 0xffff, (r[0] >> 12) & 0xf, r[0] & 0xfff
-        cb[bad] += 1; cl[tid & 63] += 1; cu[u] += 1
-        if i < 40:
-            f = lambda x: struct.unpack("f", struct.pack("I", x & 0xffffffff))[0]
-            print(f"  block {blk} tid {tid} (wave {tid >> 6} lane {tid & 63}) piece {u} bad-mask {bad:#05x} [bits 0-7 coef fields, 8 z piece, 9 g piece, 10 item mismatch]"
-                  f" rec-sample {r[1] >> 32} issue-sample {(r[1] >> 16) & 0xffff} c0 {r[1] & 0xffff}  mu reg/mem {f(r[2] >> 32):.6g}/{f(r[2]):.6g}  m1 reg/mem {f(r[3] >> 32):.6g}/{f(r[3]):.6g}")
-    print("  by bad-mask:", dict(cb)); print("  by lane:", sorted(cl.items())); print("  by piece index:", dict(cu))

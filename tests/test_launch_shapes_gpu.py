@@ -749,7 +749,23 @@ def test_persistent_kernels_are_deterministic(ops, layer, B):
             ops.convT_s2_wgrad(None, None, dw, False, 1, x16=small16, dy16=big16)
         return (dw,)
 
-    for fn in (fwd, dgrad, wgrad):
+    fns = [fwd, dgrad, wgrad]
+    if kind == "convT" and ops.convT_s2_dgrad_bn_supported(B, s, s, cb, cs, 1):
+        # the BWDNORM form itself (lg_convT_s2_dgrad_bn; round 5: the record's fields are wave-uniform scalars): the build whose
+        # packed subtraction lost m1 differed in some hundred elements on EVERY launch at a sixteenth of this batch
+        g16 = _rand((B, 2 * s, 2 * s, cb), 85).to(torch.bfloat16)
+        zb16 = (_rand((B, 2 * s, 2 * s, cb), 86, 1.5) + _rand((B, 1, 1, 1), 87)).to(torch.bfloat16)
+        stb = ops.instnorm_stats(zb16.float(), gm, bt, 0, ALPHA)
+        coef = torch.empty(B, 8, device="cuda")
+        coef[:, 0], coef[:, 1], coef[:, 2], coef[:, 3] = stb[:, 0], stb[:, 4], stb[:, 2], stb[:, 3]
+        coef[:, 4] = 1e-3 * _rand((B,), 88); coef[:, 5] = 1e-3 * _rand((B,), 89); coef[:, 6] = 1e-10; coef[:, 7] = -1e-10
+
+        def dgrad_bn():
+            g, p = ops.convT_s2_dgrad_bn(zb16, g16, coef, ALPHA, pack, cs, fuse=(zl16, stl, ALPHA))
+            assert "BWDNORM" in ops.last_kernel()
+            return g, p.buf[:B * p.nparts * 16].clone()
+        fns.append(dgrad_bn)
+    for fn in fns:
         first = [t.clone() for t in fn()]
         for rep in range(2):
             again = fn()

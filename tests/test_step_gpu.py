@@ -30,14 +30,19 @@ from oracle import np_oracle as O
 
 pytestmark = pytest.mark.gpu
 
+# 1-element tensors (the gamma / beta gradients of InstanceNormalization, instance.py:105-128) are sums of ~10^5 .. 10^8 summands with heavy
+# cancellation; their error is bounded against the SUMMANDS, not against the value or the model's largest gradient (rounds 1-4: a floor
+# of 0.22 x the largest gradient — a sign or scale error of most of these scalars passed it).  The oracle exports, per scalar, the L2 norm
+# of its summands t (ref["scalar_scale"]: sqrt(sum t^2) of t = g' c / s for gamma, t = g' for beta): an independent relative error eps
+# per summand moves the sum by eps x L2, and that is what is measured — |kernel - oracle| / L2 over every scalar of every whole-step test
+# (117 comparisons against the bf16-emulating oracle, LG_SCALAR_REPORT=1): at most 0.067, i.e. the 1e-2 .. 7e-2 per-element noise
+# of the bf16 chains (tests/replay.py holds every single call to 2e-6 x the L1 norm).  Bound: grad_rms x |exact| + sl2 x L2 with sl2 = 0.15
+# (bf16 vs the emulating oracle), 0.5 (bf16 vs fp64: measured <= 0.25).  A sign or scale error of a scalar is caught whenever
+# |exact| > ~0.08 L2 — all but the few scalars whose value is itself inside the noise of a bf16 step (e.g. the last decoder level's
+# beta: |exact| = 0.085 L2).  sfloor (x the model's largest gradient) remains only for references that carry no scale.
 TOLS = {"f32": dict(img=2e-5, loss=2e-5, grad_med=2e-5, grad_rms=5e-3, sfloor=2e-4),
-        "bf16": dict(img=6e-2, loss=2e-2, grad_med=0.2, grad_rms=0.5, sfloor=0.4),   # vs fp64: loose, secondary
-        # sfloor (1-element tensors: gamma / beta gradients, sums with heavy cancellation, bounded against the model's largest
-        # gradient): the EMULATING ORACLE ITSELF moves by 0.11 of that scale on such a scalar when the images it is fed at the model
-        # boundaries change in the last fp32 bit (round 3: the final layer's kernel began to add its taps in the opposite kx order —
-        # Adjuster norm beta at 128x128: oracle 0.011329 -> 0.009519, kernels 0.011319 -> 0.011492; tests/diagnostics/scalar_grad_noise.py).
-        # Twice that movement is the floor of this comparison; the tight checks are call by call (test_step_replay_gpu.py).
-        "bf16_emu": dict(img=4e-2, loss=2e-3, grad_med=4e-2, grad_rms=8e-2, sfloor=0.22)}
+        "bf16": dict(img=6e-2, loss=2e-2, grad_med=0.2, grad_rms=0.5, sfloor=0.4, sl2=0.5),   # vs fp64: loose, secondary
+        "bf16_emu": dict(img=4e-2, loss=2e-3, grad_med=4e-2, grad_rms=8e-2, sfloor=0.06, sl2=0.15)}
 
 
 def emu_reference(cfg, W, b, inp, fake, adj):
@@ -133,7 +138,10 @@ def check_grads(tr, ref, sets, tol, tag="", only=None):
                 if os.environ.get("LG_SCALAR_REPORT"):
                     print(f"SCALAR {tag} {m}[{i}] got {got[0]:.6e} exp {exp[0]:.6e} d {d[0]:.3e} gmax {gmax:.3e} d/gmax {abs(d[0]) / gmax:.3e}"
                           + (f" l1 {sc[0]:.3e} l2 {sc[1]:.3e} d/l1 {abs(d[0]) / sc[0]:.3e} d/l2 {abs(d[0]) / sc[1]:.3e}" if sc else ""))
-                assert abs(d[0]) <= tol["grad_rms"] * abs(exp[0]) + tol["sfloor"] * gmax, (tag, m, i, d[0], exp[0], gmax)
+                if sc is not None and "sl2" in tol:
+                    assert abs(d[0]) <= tol["grad_rms"] * abs(exp[0]) + tol["sl2"] * sc[1], (tag, m, i, d[0], exp[0], sc)
+                else:
+                    assert abs(d[0]) <= tol["grad_rms"] * abs(exp[0]) + tol["sfloor"] * gmax, (tag, m, i, d[0], exp[0], gmax)
             else:
                 rms = np.sqrt((d * d).mean()) / (np.sqrt((exp * exp).mean()) + 1e-30)
                 assert rms <= tol["grad_rms"], (tag, m, i, rms)
@@ -265,6 +273,25 @@ def test_step_full_channels_one_step(mfma, init_dim):
     check_grads(tr, ref, (("D", "dD"), ("G", "dG"), ("A", "dA")), tol)
     if mfma == "bf16":
         check_emu(tr, cfg, W, 11, inp, fake, adj, lg, ld, la)
+
+
+def test_c1_at_its_batch_f32():
+    """BASELINE config C1 at its stated size on the HIP path: 64 x 64 images, batch 16, 40 conditions, reference channel widths, exact
+    f32, the whole G + D + Adjuster step against the fp64 oracle (the configuration the reference can run on a CPU; until round 5 it
+    ran here at B = 2 only)."""
+    tol = dict(TOLS["f32"])
+    tol["grad_med"] = tol["grad_rms"]   # (LeakyReLU sign flips at fp32 rounding distance from zero, see test_step_full_channels_one_step)
+    cfg = O.Cfg(init_dim=4, cond_dim=40, batch_size=16)
+    W = perturbed(cfg, 11)
+    tr = build(cfg, W, "f32")
+    inp = f32_round(O.make_inputs(cfg, 16, seed=17))
+    ref = O.step_gradients(cfg, W, 11, inp)
+    fake, adj, lg, ld, la = tr.train_step_from_inputs(11, dev_inputs(inp))
+    assert np.abs(fake.cpu().numpy() - ref["fake_image"]).max() < tol["img"]
+    assert np.abs(adj.cpu().numpy() - ref["adj_image"]).max() < tol["img"]
+    for got, key in ((lg, "gen_loss"), (ld, "disc_loss"), (la, "adj_loss")):
+        assert abs(got.item() - ref[key]) < tol["loss"] * abs(ref[key]), (key, got.item(), ref[key])
+    check_grads(tr, ref, (("D", "dD"), ("G", "dG"), ("A", "dA")), tol, tag="C1 B=16")
 
 
 def test_graph_replay_is_bit_exact():
