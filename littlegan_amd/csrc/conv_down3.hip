@@ -81,6 +81,7 @@ struct D3Params {
   const __bf16* gsrc;  // NORM = 2 (BWDNORM): src is the raw output z of THIS level, gsrc the gradient g w.r.t. its normalised + activated
   const float* bcoef;  //   map, bcoef the per-sample records of lg_instnorm_bwd_coef: the operand dz is formed while the halo is staged
   unsigned long long* clk;  // clock census (runtime.hip: lg_set_clock_census) or null
+  int slice_major;     // experiment (round 5, LG_D3_SLICE_MAJOR): the source is [B][Cs/16][Hs][Ws][16] (channel-slice-major) instead of NHWC
   int lds_order;       // 1: halo pieces dealt to the threads in LDS order (the round-2 map; LG_D3_LDS_ORDER, A/B), 0: in memory order
   int stagger;         // start delay of the odd-slot block in ~1024-cycle units
   unsigned long long* stamps;  // diagnostic build only (LG_D3_STAMPS): [block][64] s_memtime stamps of wave 0
@@ -246,21 +247,25 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
       const int sy = 2 * it.y0 - 1 + (pyx[u] >> 8), sx = 2 * it.x0 - 1 + (pyx[u] & (PAIR ? 127 : 255));
       const int sl = PAIR ? (pyx[u] >> 7) & 1 : 0;   // PAIR: second sample of the tile
       const bool ok = pl[u] >= 0 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
-      hoff[u] = ok ? (unsigned)((((sl * p.Hs + sy) * p.Ws + sx) * p.Cs + half8) * 2) : OOB;   // (+ 2 c0 < 2^31 keeps OOB out of range)
+      // slice-major source: a pixel of a slice is 32 contiguous bytes, a slice a plane of Hs x Ws x 32 B (the channel offset c0 of issue() is
+      // rescaled there); NHWC: the pixel's Cs x 2 bytes, 32 of them used per slice
+      hoff[u] = ok ? (p.slice_major ? (unsigned)(sl * p.Hs * p.Ws * p.Cs * 2 + ((sy * p.Ws + sx) * KC + half8) * 2)
+                                    : (unsigned)((((sl * p.Hs + sy) * p.Ws + sx) * p.Cs + half8) * 2)) : OOB;   // (+ 2 c0 < 2^31 keeps OOB out of range)
     }
   };
+  const unsigned cmul = p.slice_major ? (unsigned)(p.Hs * p.Ws * 2) : 2u;   // bytes per channel step of the slice offset: c0 * cmul
   auto issue = [&](const Item& it, int c0, u32x4 (&v)[PPT]) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16*>(p.src + (long long)it.n * sample_elems), 0, (PAIR ? 2 : 1) * sample_elems * 2, 0x00027000);
 #pragma unroll
-    for (int u = 0; u < PPT; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hoff[u] + (unsigned)(c0 * 2), 0, LG_D3_HALO_AUX));
+    for (int u = 0; u < PPT; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hoff[u] + (unsigned)c0 * cmul, 0, LG_D3_HALO_AUX));
   };
   auto issue_g = [&](const Item& it, int c0, u32x4 (&v)[NORM == 2 ? PPT : 1]) __attribute__((always_inline)) {   // BWDNORM: the same pieces of g
     if constexpr (NORM == 2) {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<__bf16*>(p.gsrc + (long long)it.n * sample_elems), 0, sample_elems * 2, 0x00027000);
 #pragma unroll
-      for (int u = 0; u < PPT; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hoff[u] + (unsigned)(c0 * 2), 0, LG_D3_HALO_AUX));
+      for (int u = 0; u < PPT; ++u) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hoff[u] + (unsigned)c0 * cmul, 0, LG_D3_HALO_AUX));
     }
   };
   u32x4 gv[NORM == 2 ? PPT : 1];
@@ -664,6 +669,7 @@ static int down3_launch(const void* src16, const void* wpack, const float* bias,
   p.gsrc = (const __bf16*)g16; p.bcoef = bcoef;
   p.clk = lg_clock_census();
   { static int lo = -1; if (lo < 0) lo = lg_env_flag("LG_D3_LDS_ORDER") ? 1 : 0; p.lds_order = lo; }   // (cached per call site)
+  { static int sm = -1; if (sm < 0) sm = lg_env_flag("LG_D3_SLICE_MAJOR") ? 1 : 0; p.slice_major = (sm && !pair && !nstats && !g16) ? 1 : 0; }   // layout experiment
   static int bpc = 0;   // resident blocks per CU
   if (!bpc) {
     bpc = 2;
