@@ -45,7 +45,7 @@ template <int N, class Fn>
 __device__ __forceinline__ void lg_static_for(Fn&& fn) { lg_static_for_(std::make_integer_sequence<int, N>{}, fn); }
 
 constexpr int TH = 8, TW = 16, HHT = TH + 2, HWT = TW + 2, NPX = HHT * HWT;  // 10 x 18 = 180 halo pixels
-constexpr int RING_DEFAULT = 8;
+constexpr int RING = 8;
 #ifndef LG_U3_SCHED
 #define LG_U3_SCHED 1   // 0: fragment step in three pinned groups; 1: interleaved by sched_group_barrier (MFMA, LDS read, ...)
 #endif
@@ -53,12 +53,7 @@ constexpr int RING_DEFAULT = 8;
 // NTT = tiles per workgroup step.  Waves = NTT * WN * 4 classes: 8 (one workgroup per CU) or, for N = 32 with ONE tile per step,
 // 4 (TWO independent workgroups per CU, 58 KB of LDS each: one's staging / row-store / barrier phases fall into the other's
 // MFMA phase — r3 stamps of the 8-wave form at N = 32: 49 % of a step is not MFMA time and nothing overlaps it).
-// AL (round 5, the N = 32 level): the output-tile staging area ALIASES the halo — a step is class loop | barrier | stage | barrier | rows out |
-// barrier | next halo (prefetched in registers) committed | barrier — 34 KB of LDS and a 4-fragment weight ring (<= 168 VGPRs): THREE
-// workgroups per CU instead of two; the four serial phases of one workgroup fall into the class loops of the two others.
-template <int CS, int N, int NTT = 2 / (N / 32), bool AL = false> struct Cfg {
-  static constexpr bool ALIAS = AL;
-  static constexpr int RING = AL ? 4 : RING_DEFAULT;
+template <int CS, int N, int NTT = 2 / (N / 32)> struct Cfg {
   static constexpr int WN = N / 32;               // column waves per tile (2 | 1)
   static constexpr int NT = NTT;                  // tiles per workgroup step
   static constexpr int NWAVES = NT * WN * 4, THREADS = 64 * NWAVES;
@@ -71,8 +66,8 @@ template <int CS, int N, int NTT = 2 / (N / 32), bool AL = false> struct Cfg {
   static constexpr int CROW = N * 2;              // output pixel row in the staging area (bytes): 128 | 64
   static constexpr int CB = OPX * CROW;           // staging bytes per tile
   static constexpr int KB = CS / 16;              // k-steps
-  static constexpr int C_OFF = AL ? 0 : NT * HB;
-  static constexpr int SRED_OFF = AL ? (CB > HB ? NT * CB : NT * HB) : C_OFF + NT * CB;
+  static constexpr int C_OFF = NT * HB;
+  static constexpr int SRED_OFF = C_OFF + NT * CB;
   static constexpr int SBIAS_OFF = SRED_OFF + THREADS * 8;    // per-thread {sum d, sum d^2} floats of the current step
   static constexpr int LDS = SBIAS_OFF + N * 4;
   static constexpr int PIECES = NT * NPX * (CS * 2 / 16);       // 16-B halo pieces per step
@@ -105,12 +100,10 @@ constexpr int ntaps_of(int cls) { return nk(cls >> 1) * nk(cls & 1); }
 constexpr int tap_k(int p, int a) { return p ? 2 * a : 2 * a + 1; }
 constexpr int tap_d(int p, int a) { return (p + 1 - tap_k(p, a)) / 2; }
 
-template <int CS, int N, bool STATS, bool FUSE = false, int NTT = 2 / (N / 32), bool AL = false>
-__global__ __launch_bounds__((Cfg<CS, N, NTT, AL>::THREADS), (AL ? 3 : 2)) void conv_up3_kernel(const U3Params p) {
+template <int CS, int N, bool STATS, bool FUSE = false, int NTT = 2 / (N / 32)>
+__global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel(const U3Params p) {
   static_assert(!(STATS && FUSE), "forward moments and backward sums are never needed together");
-  static_assert(!AL || NTT == 1, "the aliased staging area exists for the one-tile-per-step form");
-  using C = Cfg<CS, N, NTT, AL>;
-  constexpr int RING = C::RING;
+  using C = Cfg<CS, N, NTT>;
   constexpr int NTH = C::THREADS, NWV = C::NWAVES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x2* sstat = reinterpret_cast<f32x2*>(smem + C::SRED_OFF);
@@ -245,7 +238,7 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT, AL>::THREADS), (AL ? 3 : 2)) void 
   // | BARRIER (halo and staging area free) | stage | halo commit | BARRIER | moments of this tile.  The stores go through a buffer
   // descriptor over the whole output: a tile that does not exist (step 0's "previous" tile, the odd tail) gets an out-of-range
   // offset and its stores are dropped — no branch in the loop.
-  constexpr bool DEFER = !FUSE && !LG_U3_NO_DEFER && !C::ALIAS;   // (LG_U3_NO_DEFER=1: the round-2 order, rows in a phase of their own — A/B builds)
+  constexpr bool DEFER = !FUSE && !LG_U3_NO_DEFER;   // (LG_U3_NO_DEFER=1: the round-2 order, rows in a phase of their own — A/B builds)
   constexpr int PPO_ = C::CROW / 16, TOT_ = C::NT * C::OPX * PPO_, NPC = TOT_ / NTH;   // pieces per thread and step (8)
   // Piece q8 of thread tid is output pixel o = tid / PPO + q8 * (NTH / PPO) of tile (q8 * (NTH / PPO)) / OPX, 16-byte column tid % PPO:
   // ONE LDS address and ONE global offset per thread (the swizzle term does not depend on q8), everything else is an immediate or
@@ -370,7 +363,7 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT, AL>::THREADS), (AL ? 3 : 2)) void 
     //  every ring wait of the first fragments also waited for them.)  Last step: the current halo again — valid addresses, result
     // unused, no branch around the loads.
     issue(more ? s + 1 : s, hv);
-    if constexpr (DEFER || C::ALIAS) __syncthreads();  // every halo read of this step and every row read of the previous tile is done (ALIAS: the staging pass overwrites the halo)
+    if constexpr (DEFER) __syncthreads();  // every halo read of this step and every row read of the previous tile is done
     // ---- this wave's class into the output-tile staging area: acc[i][e] = channel (e&3) + 8*(e>>2) + 4*h of pixel m ----------
     {
       char* Cst = smem + C::C_OFF + tsel * C::CB;
@@ -432,7 +425,7 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT, AL>::THREADS), (AL ? 3 : 2)) void 
     if constexpr (!DEFER) __syncthreads();  // every class of the tile(s) is staged, every halo read is done
     U3_STAMP();  // barrier 1 passed
 
-    if constexpr (!C::ALIAS) { if (more) commit(hv); }
+    if (more) commit(hv);
     if constexpr (DEFER) {
       __syncthreads();  // tile staged, next halo in place; its rows leave inside the next class loop (or below, after the last step)
 #pragma unroll
@@ -513,11 +506,7 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT, AL>::THREADS), (AL ? 3 : 2)) void 
     (void)live;
     U3_STAMP();  // rows out
     if constexpr (C::ROT) cls = rot_class(wid + rsh + s + 1);
-    if constexpr (C::ALIAS) {
-      __syncthreads();        // every row has left the shared region
-      if (more) commit(hv);   // the next halo, in registers since the end of the class loop
-      __syncthreads();
-    } else if constexpr (!DEFER) __syncthreads();  // next halo complete, staging area free again
+    if constexpr (!DEFER) __syncthreads();  // next halo complete, staging area free again
   }
   if constexpr (DEFER) {  // the last tile's rows
 #pragma unroll
@@ -525,24 +514,22 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT, AL>::THREADS), (AL ? 3 : 2)) void 
   }
 }
 
-template <int CS, int N, int NTT = 2 / (N / 32), bool AL = false>
+template <int CS, int N, int NTT = 2 / (N / 32)>
 int launch_up3(U3Params p, bool stats, hipStream_t st, bool fuse = false) {
-  using C = Cfg<CS, N, NTT, AL>;
+  using C = Cfg<CS, N, NTT>;
   static bool attr_set = false;
-  static int al_wgs = 0;
-  if (!al_wgs) { const char* e = getenv("LG_U3_ALIAS_WGS"); al_wgs = (e && atoi(e) >= 1 && atoi(e) <= 3) ? atoi(e) : 3; }   // A/B: resident workgroups per CU of the aliased form
-  const int nblk = (C::NWAVES == 8 ? 1 : AL ? al_wgs : 2) * lg_grid_cus();  // one 8-wave workgroup per CU, or two / three independent 4-wave ones
+  const int nblk = (C::NWAVES == 8 ? 1 : 2) * lg_grid_cus();  // one 8-wave workgroup per CU, or two independent 4-wave ones
   if (!attr_set) {
     attr_set = true;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, true, false, NTT, AL>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false, false, NTT, AL>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false, true, NTT, AL>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, true, false, NTT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false, false, NTT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false, true, NTT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
   }
   const int nsteps = (p.nitems + C::NT - 1) / C::NT;
   const int grid = nsteps < nblk ? nsteps : nblk;
-  if (fuse) hipLaunchKernelGGL((conv_up3_kernel<CS, N, false, true, NTT, AL>), dim3(grid), dim3(C::THREADS), C::LDS, st, p);
-  else if (stats) hipLaunchKernelGGL((conv_up3_kernel<CS, N, true, false, NTT, AL>), dim3(grid), dim3(C::THREADS), C::LDS, st, p);
-  else hipLaunchKernelGGL((conv_up3_kernel<CS, N, false, false, NTT, AL>), dim3(grid), dim3(C::THREADS), C::LDS, st, p);
+  if (fuse) hipLaunchKernelGGL((conv_up3_kernel<CS, N, false, true, NTT>), dim3(grid), dim3(C::THREADS), C::LDS, st, p);
+  else if (stats) hipLaunchKernelGGL((conv_up3_kernel<CS, N, true, false, NTT>), dim3(grid), dim3(C::THREADS), C::LDS, st, p);
+  else hipLaunchKernelGGL((conv_up3_kernel<CS, N, false, false, NTT>), dim3(grid), dim3(C::THREADS), C::LDS, st, p);
   return LG_OK;
 }
 
@@ -580,9 +567,8 @@ extern "C" int lg_conv_up3_nf_try(const void* src16, const void* wpack_up, const
 #endif
   // N = 32: two independent 4-wave workgroups per CU, one tile per step (LG_U3_T4_8W=1: the round-2 form, one 8-wave workgroup
   // with two tiles per step)
-  static int t4_8w = -1, no_alias = -1;
+  static int t4_8w = -1;
   if (t4_8w < 0) t4_8w = lg_env_flag("LG_U3_T4_8W") ? 1 : 0;
-  if (no_alias < 0) no_alias = lg_env_flag("LG_U3_NO_ALIAS") ? 1 : 0;   // A/B: the round-3/4 form (separate staging area, two workgroups per CU)
   { static int ro = -1; if (ro < 0) { const char* e = getenv("LG_U3_ROTOFF"); ro = e ? (atoi(e) & 3) : 0; } p.rotoff = ro; }   // A/B (round 5, measured: 141 - 145 us for offsets 0 / 1 / 2 — no effect, default 0)
   // the norm-backward sums are produced by the one-tile-per-step forms only: with two tiles per step a thread's row sweep covers
   // both tiles, i.e. possibly two samples, and the per-thread sums would mix them (no layer of the step asks for that form)
@@ -596,10 +582,9 @@ extern "C" int lg_conv_up3_nf_try(const void* src16, const void* wpack_up, const
   hipStream_t st = (hipStream_t)stream;
   if (Cs == 128) launch_up3<128, 64>(p, stats, st, fuse);
   else if (t4_8w) launch_up3<64, 32>(p, stats, st, fuse);
-  else if (no_alias) launch_up3<64, 32, 1>(p, stats, st, fuse);
-  else launch_up3<64, 32, 1, true>(p, stats, st, fuse);
+  else launch_up3<64, 32, 1>(p, stats, st, fuse);
   LG_CHECK_LAUNCH("lg_conv_up3");
-  lg_note_kernel(Cs == 128 ? "conv_up3_kernel<128,64>" : t4_8w ? "conv_up3_kernel<64,32>" : no_alias ? "conv_up3_kernel<64,32,4w>" : "conv_up3_kernel<64,32,4w,alias>");
+  lg_note_kernel(Cs == 128 ? "conv_up3_kernel<128,64>" : t4_8w ? "conv_up3_kernel<64,32>" : "conv_up3_kernel<64,32,4w>");
   if (stats || fuse) *nparts_out = p.tpi;
   return LG_OK;
 }

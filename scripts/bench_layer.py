@@ -12,7 +12,7 @@ LAYERS = [  # name, kind, Hs, cb, cs
     ("conv4 fwd 16->8", "down", 8, 256, 384), ("final s1t 128", "s1t", 128, 3, 32), ("conv1 dgrad 64->128", "up", 64, 3, 64),
     ("wgrad 16/32 (128,256)", "wgrad", 16, 128, 256), ("wgrad 32/64 (64,128)", "wgrad", 32, 64, 128), ("wgrad 64/128 (32,64)", "wgrad", 64, 32, 64),
     ("wgrad 8/16 (256,384)", "wgrad", 8, 256, 384),
-    ("convT4 dgrad 128->64", "ddown", 64, 32, 64), ("convT3 dgrad 64->32", "ddown", 32, 64, 128), ("convT2 dgrad 32->16", "ddown", 16, 128, 256),
+    ("convT1 dgrad 16->8", "ddown", 8, 256, 384), ("convT4 dgrad 128->64", "ddown", 64, 32, 64), ("convT3 dgrad 64->32", "ddown", 32, 64, 128), ("convT2 dgrad 32->16", "ddown", 16, 128, 256),
     ("conv2 dgrad 32->64", "dup", 32, 64, 128), ("conv3 dgrad 16->32", "dup", 16, 128, 256), ("conv4 dgrad 8->16", "dup", 8, 256, 384),
 ]
 FUSE = os.environ.get("LG_FUSE", "0") == "1"  # data-gradient cases: with the norm-backward sums of the layer below in the epilogue
