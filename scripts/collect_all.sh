@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-R=${LG_ROUND:-r4}
+R=${LG_ROUND:-r5}
 export LG_ROUND=$R
 bash scripts/collect_profiles.sh > gpurun_out/${R}_collect.log 2>&1 || { tail -20 gpurun_out/${R}_collect.log; exit 1; }
 cp gpurun_out/${R}prof/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json   # bench.py reads the traffic of its dominant kernel from here

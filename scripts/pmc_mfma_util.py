@@ -32,9 +32,19 @@ def main():
         if busy <= 0:
             continue
         lines.append(f"| `{name}` | {n} | {100.0 * busy / (gui * 1024.0):.1f} | {gui / dur:.2f} | {dur / 1e6:.2f} |")
+    if "--stack" in sys.argv:   # the Generator's forward stack (scripts/bench_gstack.py): one time-weighted figure over its five conv kernels
+        stack = [k for k in agg if k.startswith(("conv_up4_kernel", "conv_up3_kernel", "s1t_fwd_rows_kernel"))]
+        busy = sum(agg[k][0] for k in stack); gui = sum(agg[k][1] for k in stack); dur = sum(agg[k][2] for k in stack)
+        if gui > 0:
+            lines.append(f"| **the five forward kernels, time-weighted** | {sum(agg[k][3] for k in stack)} | **{100.0 * busy / (gui * 1024.0):.1f}** | {gui / dur:.2f} | {dur / 1e6:.2f} |")
     out = "\n".join(lines)
     print(out)
-    if len(sys.argv) > 2:
+    if len(sys.argv) > 2 and not sys.argv[2].startswith("--"):
+        src = ("python scripts/bench_gstack.py (B = 256, forward launches of the Generator's transposed-conv stack only; apply / pack launches carry no MFMA work and are left out)"
+               if "--stack" in sys.argv else None)
+        if src:
+            open(sys.argv[2], "w").write(out + "\n\nSource: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- " + src + " (counter pass serialises kernels: the clock column is the clock of THIS pass).\n")
+            return
         open(sys.argv[2], "w").write(out + "\n\nSource: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -- python bench.py "
                                      "--steps 2 --warmup 1 --no-cpu-baseline (counter pass serialises kernels; durations are longer than in the timed run).\n")
 
