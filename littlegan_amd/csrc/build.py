@@ -8,7 +8,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 SOURCES = ["capi.hip", "conv_igemm.hip", "conv_halo.hip", "conv_down3.hip", "conv_up3.hip", "n3_kernels.hip", "n3_pgemm.hip", "wgrad_igemm.hip", "pack.hip", "norm.hip", "dense.hip", "heads.hip", "loss_optim.hip", "augment.hip", "fid.hip", "wgrad_at.hip", "wgrad_at32.hip", "n3_rows.hip", "skinny_mfma.hip", "conv_up4.hip", "runtime.hip"]
 LIB = os.path.join(PKG, "liblittlegan_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# -packed-fp32-ops (round 5): no v_pk_{add,mul,fma}_f32 anywhere in the library.  The one kernel build that ever gave launch-to-launch
+# different results lost the low half of a packed fp32 subtraction (VGPR pair, high-register select) with a second wave on the SIMD; without
+# packed fp32 instructions the same source is deterministic, and the whole library is as fast (C3 10.944 / 10.948 against 10.955 / 10.958 ms,
+# C2 8.912 / 8.906, C5 39.89 / 39.96: scripts/probe/nopk_ab.sh) — the instruction class is simply not generated.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _stale(out, deps):

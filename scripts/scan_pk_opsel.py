@@ -32,9 +32,7 @@ def scan_text(lines):
     return tot, per, ex
 
 
-def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    lib = args[0] if args else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "littlegan_amd", "liblittlegan_hip.so")
+def scan_library(lib):
     tmp = tempfile.mkdtemp(prefix="lgscan")
     try:
         shutil.copy(lib, os.path.join(tmp, "lib.so"))
@@ -48,11 +46,18 @@ def main():
                 ex.setdefault(k, v)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    return tot, per, ex
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    lib = args[0] if args else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "littlegan_amd", "liblittlegan_hip.so")
+    tot, per, ex = scan_library(lib)
     print("packed fp32 instructions in the library:", dict(tot))
     print("kernels in which a LOW result reads the HIGH register of a VGPR pair:", len(per))
     for k, v in per.most_common():
         print(f"  {v:5d}  {k[:120]}\n         e.g. {ex[k]}")
-    if "--fail" in sys.argv and per:
+    if "--fail" in sys.argv and (per or tot):
         sys.exit(1)
 
 

@@ -78,3 +78,17 @@ def test_argument_validation_without_gpu(lib):
     assert h.lg_conv_pack_bytes(3, 64, 0) == 5 * 64 * 16 * 4 + 25 * 32 * 64 * 4 + 75 * 64 * 4  # + verbatim f32 kernel
     with pytest.raises(lib.LittleGanHipError):
         lib.check(-1, "x")
+
+
+def test_library_holds_no_packed_fp32_instruction(lib):
+    """Round 5: the one build that ever gave launch-to-launch different results lost the low half of a packed fp32
+    subtraction (`v_pk_add_f32` on a VGPR pair with a high-register select) when a second wave shared the SIMD.  The library is built
+    with -packed-fp32-ops: no `v_pk_{add,mul,fma}_f32` may appear in any gfx950 code object of the product library (disassembled here
+    with llvm-objdump, no GPU needed)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import scan_pk_opsel
+    if not os.path.exists(scan_pk_opsel.OBJDUMP):
+        pytest.skip("llvm-objdump not found")
+    tot, per, _ = scan_pk_opsel.scan_library(os.path.join(ROOT, "littlegan_amd", "liblittlegan_hip.so"))
+    assert not tot, f"packed fp32 instructions in the product library: {dict(tot)} (kernels with the failing operand form: {len(per)})"
