@@ -124,7 +124,7 @@ constexpr int toff_bytes(int t) {  // tap t = ky*5+kx: LDS byte offset of its so
 // Two facts from the way: (1) the staging arithmetic must be pinned behind the tap loop (see commit below); (2) the per-item
 // coefficient record is read through the constant address space (lg_as_const, lg_common.h: as a plain load hipcc made it a VECTOR
 // load inside the item loop, `s_waitcnt vmcnt(0)` at every item boundary) AND every field is made wave-uniform explicitly
-// (lg_uniform), so that the staging arithmetic takes scalar operands.  The vector-load build (-DLG_D3_COEF_PLAIN reproduces it) was
+// (lg_uniform), so that the staging arithmetic takes scalar operands.  The vector-load build (-DLG_D3_COEF_PLAIN at commit 43a08f2) was
 // NOT deterministic with two blocks per CU: hipcc kept the record as per-lane copies paired in 64-bit registers and formed g' - m1 as
 // a packed fp32 subtraction selecting the pair's HIGH register; read back through one-hot weights (tests/diagnostics/bwdnorm_probe.py)
 // every wrong operand element — 82 of 82 — was the LOW result of that instruction, bit-equal to the value with m1 not subtracted.
