@@ -36,9 +36,6 @@
 #ifndef LG_U3_NO_DEFER
 #define LG_U3_NO_DEFER 0
 #endif
-#ifndef LG_U3_FUSE_DEFER
-#define LG_U3_FUSE_DEFER 1   // round 5: the FUSE form (data gradient + norm-backward sums) also sends its rows out inside the next class loop (0: A/B builds)
-#endif
 
 namespace {
 
@@ -48,7 +45,7 @@ template <int N, class Fn>
 __device__ __forceinline__ void lg_static_for(Fn&& fn) { lg_static_for_(std::make_integer_sequence<int, N>{}, fn); }
 
 constexpr int TH = 8, TW = 16, HHT = TH + 2, HWT = TW + 2, NPX = HHT * HWT;  // 10 x 18 = 180 halo pixels
-constexpr int RING_DEFAULT = 8;
+constexpr int RING = 8;
 #ifndef LG_U3_SCHED
 #define LG_U3_SCHED 1   // 0: fragment step in three pinned groups; 1: interleaved by sched_group_barrier (MFMA, LDS read, ...)
 #endif
@@ -108,8 +105,6 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
   static_assert(!(STATS && FUSE), "forward moments and backward sums are never needed together");
   using C = Cfg<CS, N, NTT>;
   constexpr int NTH = C::THREADS, NWV = C::NWAVES;
-  // weight-fragment ring: 8 deep; the FUSE form with the deferred row sweep (round 5) runs it 4 deep to pay for its z registers
-  constexpr int RING = (FUSE && LG_U3_FUSE_DEFER && !LG_U3_NO_DEFER && C::NT == 1) ? 4 : RING_DEFAULT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x2* sstat = reinterpret_cast<f32x2*>(smem + C::SRED_OFF);
   float* sbias = reinterpret_cast<float*>(smem + C::SBIAS_OFF);
@@ -243,18 +238,7 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
   // | BARRIER (halo and staging area free) | stage | halo commit | BARRIER | moments of this tile.  The stores go through a buffer
   // descriptor over the whole output: a tile that does not exist (step 0's "previous" tile, the odd tail) gets an out-of-range
   // offset and its stores are dropped — no branch in the loop.
-  constexpr bool DEFER = !LG_U3_NO_DEFER && (!FUSE || (LG_U3_FUSE_DEFER && C::NT == 1));   // (LG_U3_NO_DEFER=1: the round-2 order, rows in a phase of their own — A/B builds)
-  // FUSE + DEFER (round 5): the norm-backward sums of tile s are formed where its rows leave — inside the class loop of step s + 1.  The z piece
-  // that belongs to row piece q is requested (buffer load over nf.z with the STORE's offsets: a tile that does not exist reads zeros and its
-  // sums are discarded) where piece q is read from the staging area, and accumulated one STEP later where it is stored, in two halves spread
-  // over two fragments (72 VALU operations per piece against 2 x 128 matrix cycles): two z registers alternate, nothing else is carried.
-  // The sums of tile s are reduced and written behind the first barrier of step s + 1 (one wave; the others stage).
-  constexpr bool FDEF = FUSE && DEFER;
-  float nfa1 = 0.f, nfa2 = 0.f;                       // this thread's sums over the pieces of the PREVIOUS tile
-  float pmu = 0.f, pmul = 0.f, pna = 0.f, pnb = 0.f;  // ... its sample's statistics (wave-uniform)
-  int ptn = 0, pty0 = 0, ptx0 = 0; bool plive = false;
-  u32x4 zv[2];
-  (void)nfa1; (void)nfa2; (void)pmu; (void)pmul; (void)pna; (void)pnb; (void)ptn; (void)pty0; (void)ptx0; (void)plive; (void)zv;
+  constexpr bool DEFER = !FUSE && !LG_U3_NO_DEFER;   // (LG_U3_NO_DEFER=1: the round-2 order, rows in a phase of their own — A/B builds)
   constexpr int PPO_ = C::CROW / 16, TOT_ = C::NT * C::OPX * PPO_, NPC = TOT_ / NTH;   // pieces per thread and step (8)
   // Piece q8 of thread tid is output pixel o = tid / PPO + q8 * (NTH / PPO) of tile (q8 * (NTH / PPO)) / OPX, 16-byte column tid % PPO:
   // ONE LDS address and ONE global offset per thread (the swizzle term does not depend on q8), everything else is an immediate or
@@ -274,22 +258,6 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
   auto piece_lds = [&](int q8) {   // q8 is a compile-time constant at every call
     const int t = (q8 * OPQ) / C::OPX, oq = (q8 * OPQ) % C::OPX;
     return *reinterpret_cast<const u32x4*>(smem + plds + t * C::CB + oq * C::CROW);
-  };
-  auto piece_z = [&](int q8) {   // FDEF: the z piece under row piece q8 of the previous tile (same offsets as its store)
-    const int t = (q8 * OPQ) / C::OPX, oq = (q8 * OPQ) % C::OPX;
-    const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.nf.z), 0, (int)pnrec[t], 0x00027000);
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(zrs, pgl, (int)(pbyte[t] + (unsigned)(oq >> 5) * prow), 0));
-  };
-  auto nf_half = [&](const u32x4 g8, const u32x4 z8, int k0) {   // lg_nf_accum on elements 2 k0 .. 2 k0 + 3 (two of the piece's four dwords)
-#pragma unroll
-    for (int k = k0; k < k0 + 2; ++k) {
-      const float g0 = __builtin_bit_cast(float, g8[k] << 16), g1 = __builtin_bit_cast(float, g8[k] & 0xffff0000u);
-      const float z0 = __builtin_bit_cast(float, z8[k] << 16), z1 = __builtin_bit_cast(float, z8[k] & 0xffff0000u);
-      const float c0 = (z0 - pmu) - pmul, c1 = (z1 - pmu) - pmul;
-      const float p0 = (pna * c0 + pnb > 0.f) ? g0 : p.nf.alpha * g0, p1 = (pna * c1 + pnb > 0.f) ? g1 : p.nf.alpha * g1;
-      nfa1 += p0; nfa1 += p1;
-      nfa2 = __builtin_fmaf(p0, c0, nfa2); nfa2 = __builtin_fmaf(p1, c1, nfa2);
-    }
   };
   auto piece_store = [&](int q8, const u32x4 v) {
     const int t = (q8 * OPQ) / C::OPX, oq = (q8 * OPQ) % C::OPX;
@@ -341,23 +309,10 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
       // The pieces sit between two sched_barrier(0) at the fragment boundary.  Handed to the group pipeline below as groups of their
       // own (VMEM write, DS read), the piece read could be picked by ANY earlier "DS read" group: the whole class loop came out scrambled
       // (ring waits collapsed to vmcnt(0..3), MFMAs of different fragments interleaved, 12 min of compile time).
-      // FDEF: second half of the sums of the piece stored at the previous fragment (STEP = 2: a fragment without piece traffic of its own)
-      constexpr bool ST2 = FDEF && STEP == 2 && f >= 2 + STEP && (f - 2 - STEP) % STEP == 0 && (f - 2 - STEP) / STEP < NPC;
-      if constexpr (ST || RD || ST2) __builtin_amdgcn_sched_barrier(0);
-      if constexpr (ST2) nf_half(piece_lds((f - 2 - STEP) / STEP), zv[((f - 2 - STEP) / STEP) & 1], 2);   // (re-read from the staging area: nothing carried)
-      if constexpr (ST) {
-        constexpr int q = (f - 1 - STEP) / STEP;
-        if constexpr (FDEF) {
-          nf_half(rv, zv[q & 1], 0);
-          if constexpr (STEP != 2) nf_half(rv, zv[q & 1], 2);
-        }
-        piece_store(q, rv);   // one register: piece q leaves, piece q + 1 is read behind it
-      }
-      if constexpr (RD) {
-        rv = piece_lds((f - 1) / STEP);
-        if constexpr (FDEF) zv[((f - 1) / STEP) & 1] = piece_z((f - 1) / STEP);
-      }
-      if constexpr (ST || RD || ST2) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ST || RD) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ST) piece_store((f - 1 - STEP) / STEP, rv);   // one register: piece q leaves, piece q + 1 is read behind it
+      if constexpr (RD) rv = piece_lds((f - 1) / STEP);
+      if constexpr (ST || RD) __builtin_amdgcn_sched_barrier(0);
       if constexpr (LG_U3_SCHED == 0) {
         __builtin_amdgcn_sched_barrier(0);
       } else {  // one MFMA, one LDS read in its shadow, ..., the ring refill behind the last MFMA (see conv_down3.hip)
@@ -408,28 +363,7 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
     //  every ring wait of the first fragments also waited for them.)  Last step: the current halo again — valid addresses, result
     // unused, no branch around the loads.
     issue(more ? s + 1 : s, hv);
-    auto nf_flush = [&]() {   // FDEF: the previous tile's sums — per-thread partials into LDS, one wave adds them up and writes the record
-      sstat[tid] = f32x2{nfa1, nfa2};
-      nfa1 = 0.f; nfa2 = 0.f;
-    };
-    auto nf_write = [&]() {
-      if (wid == 0 && plive) {
-        double S1 = 0.0, S2 = 0.0;
-#pragma unroll
-        for (int w = 0; w < NWV; ++w) {
-          const f32x2 v = sstat[w * 64 + lane];
-          S1 += (double)v[0]; S2 += (double)v[1];
-        }
-        S1 = lg_wave_sum_d(S1); S2 = lg_wave_sum_d(S2);
-        if (lane == 0) {
-          double* o = p.nf.part + ((long long)ptn * p.tpi + (pty0 / TH) * p.tpi_x + ptx0 / TW) * 2;
-          o[0] = S1; o[1] = S2;
-        }
-      }
-    };
-    if constexpr (FDEF) nf_flush();
     if constexpr (DEFER) __syncthreads();  // every halo read of this step and every row read of the previous tile is done
-    if constexpr (FDEF) nf_write();
     // ---- this wave's class into the output-tile staging area: acc[i][e] = channel (e&3) + 8*(e>>2) + 4*h of pixel m ----------
     {
       char* Cst = smem + C::C_OFF + tsel * C::CB;
@@ -473,9 +407,9 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
     constexpr int TOT = C::NT * C::OPX * PPO;         // 4096 pieces per step either way
     // FUSE: the z pieces this thread will meet in the row sweep are requested NOW — the accumulators are dead (staged), and
     // the loads land behind the barrier and the halo commit instead of in front of every use
-    u32x4 zq[(FUSE && !DEFER) ? TOT / NTH : 1];
+    u32x4 zq[FUSE ? TOT / NTH : 1];
     (void)zq;
-    if constexpr (FUSE && !DEFER) {
+    if constexpr (FUSE) {
 #pragma unroll
       for (int q8 = 0; q8 < TOT / NTH; ++q8) {
         const int q = tid + q8 * NTH;
@@ -499,11 +433,6 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
         // (readfirstlane: both ride in scalar operands of the row stores — descriptor size and scalar offset; see issue())
         pbyte[t] = (unsigned)__builtin_amdgcn_readfirstlane((int)((((long long)(tns[t] * 2 * p.Hs + 2 * ty0s[t]) * (2 * p.Ws) + 2 * tx0s[t]) * N) * 2));
         pnrec[t] = (unsigned)__builtin_amdgcn_readfirstlane((int)(tlive[t] ? out_bytes : 0u));
-      }
-      if constexpr (FDEF) {   // this tile becomes the previous one: where its sums go, and its sample's statistics (scalar loads, wave-uniform)
-        ptn = tns[0]; pty0 = ty0s[0]; ptx0 = tx0s[0]; plive = tlive[0];
-        const lg_const_f32p sp = lg_as_const(p.nf.stats + (long long)ptn * 8);
-        pmu = lg_uniform(sp[0]); pmul = lg_uniform(sp[4]); pna = lg_uniform(sp[2]); pnb = lg_uniform(sp[3]);
       }
     } else
     // ---- whole output rows out: 16 rows x (32 pixels x N channels) contiguous, 16 B per lane ------------------------------
@@ -530,7 +459,7 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
       }
       if constexpr (FUSE) sstat[tid] = f32x2{nf1, nf2};
     }
-    if constexpr (FUSE && !DEFER) {
+    if constexpr (FUSE) {
       __syncthreads();
       const int t = wid / (NWV / C::NT);
       if (wid == t * (NWV / C::NT)) {
@@ -579,33 +508,9 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
     if constexpr (C::ROT) cls = rot_class(wid + rsh + s + 1);
     if constexpr (!DEFER) __syncthreads();  // next halo complete, staging area free again
   }
-  if constexpr (DEFER) {  // the last tile's rows (FDEF: and its sums)
+  if constexpr (DEFER) {  // the last tile's rows
 #pragma unroll
-    for (int q8 = 0; q8 < NPC; ++q8) {
-      const u32x4 v = piece_lds(q8);
-      if constexpr (FDEF) {
-        const u32x4 z = piece_z(q8);
-        nf_half(v, z, 0); nf_half(v, z, 2);
-      }
-      piece_store(q8, v);
-    }
-    if constexpr (FDEF) {
-      sstat[tid] = f32x2{nfa1, nfa2};
-      __syncthreads();
-      if (wid == 0 && plive) {
-        double S1 = 0.0, S2 = 0.0;
-#pragma unroll
-        for (int w = 0; w < NWV; ++w) {
-          const f32x2 v = sstat[w * 64 + lane];
-          S1 += (double)v[0]; S2 += (double)v[1];
-        }
-        S1 = lg_wave_sum_d(S1); S2 = lg_wave_sum_d(S2);
-        if (lane == 0) {
-          double* o = p.nf.part + ((long long)ptn * p.tpi + (pty0 / TH) * p.tpi_x + ptx0 / TW) * 2;
-          o[0] = S1; o[1] = S2;
-        }
-      }
-    }
+    for (int q8 = 0; q8 < NPC; ++q8) piece_store(q8, piece_lds(q8));
   }
 }
 
