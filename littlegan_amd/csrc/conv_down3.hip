@@ -81,7 +81,7 @@ struct D3Params {
   const __bf16* gsrc;  // NORM = 2 (BWDNORM): src is the raw output z of THIS level, gsrc the gradient g w.r.t. its normalised + activated
   const float* bcoef;  //   map, bcoef the per-sample records of lg_instnorm_bwd_coef: the operand dz is formed while the halo is staged
   unsigned long long* clk;  // clock census (runtime.hip: lg_set_clock_census) or null
-  int old_lists;       // A/B (LG_D3_OLD_LISTS): the round-2 item lists lb, lb + G, ...
+  int lists;           // item lists (LG_D3_LISTS): 0 rounds with a balanced partial round (default), 1 the round-2 lists, 2 one contiguous range per XCD
   int slice_major;     // experiment (round 5, LG_D3_SLICE_MAJOR): the source is [B][Cs/16][Hs][Ws][16] (channel-slice-major) instead of NHWC
   int lds_order;       // 1: halo pieces dealt to the threads in LDS order (the round-2 map; LG_D3_LDS_ORDER, A/B), 0: in memory order
   int stagger;         // start delay of the odd-slot block in ~1024-cycle units
@@ -155,12 +155,19 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
   // count as the stride.  The round-2 lists (items lb, lb + G, ... with lb the XCD-major block rank) gave the remainder of
   // nitems / G to the LOWEST ranks = the first XCDs: at 768 items on 512 blocks (the 8 x 8 level at 2B) every block of XCDs 0-3 ran
   // two items and every block of XCDs 4-7 one — half the chip idle for the second half of the launch.
+  // Two balanced forms (p.lists, LG_D3_LISTS): 2 = the contiguous range per XCD just described; 0 (default) = ROUNDS — the whole chip sweeps the map
+  // front to back in rounds of G items as in round 2 (the producer of the map has just written it and its front is what the caches still hold), and only
+  // the LAST, partial round is dealt out as one contiguous sub-range per XCD.  1 = the round-2 lists (A/B).
   const int nx = G < 8 ? G : 8, xcd = (int)blockIdx.x % nx, xidx = (int)blockIdx.x / nx;
-  const int nbx = p.old_lists ? G : (G - xcd + nx - 1) / nx;                 // blocks of this XCD = the stride of a block's list
-  const int icnt = (p.nitems - xcd + nx - 1) / nx;                           // items of this XCD (>= nbx: grid <= nitems)
+  const bool ranges = p.lists == 2;
+  const int nbx = ranges ? (G - xcd + nx - 1) / nx : G;                      // stride of a block's list
+  const int icnt = (p.nitems - xcd + nx - 1) / nx;                           // ranges: items of this XCD (>= nbx: grid <= nitems)
   const int istart = xcd * (p.nitems / nx) + (xcd < p.nitems % nx ? xcd : p.nitems % nx);
-  const int lb = p.old_lists ? lg_xcd_remap(blockIdx.x, G) : istart + xidx;  // first item; then lb + nbx, lb + 2 nbx, ...  (old_lists: LG_D3_OLD_LISTS, A/B)
-  const int nmine = p.old_lists ? (p.nitems - lb + G - 1) / G : (icnt - xidx + nbx - 1) / nbx;
+  const int lb = ranges ? istart + xidx : lg_xcd_remap(blockIdx.x, G);       // first item; then lb + nbx, lb + 2 nbx, ...
+  const int nfull = p.nitems / G, nrem = p.nitems - nfull * G;               // rounds: full rounds, items of the partial one
+  const int rcnt = (nrem - xcd + nx - 1) / nx;                               // ... of which this XCD takes rcnt, from rstart on
+  const int rstart = nfull * G + xcd * (nrem / nx) + (xcd < nrem % nx ? xcd : nrem % nx);
+  const int nmine = ranges ? (icnt - xidx + nbx - 1) / nbx : p.lists == 1 ? (p.nitems - lb + G - 1) / G : nfull + (xidx < rcnt ? 1 : 0);
   const int total = nmine * nchunk;
   const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();   // clock census (see the end)
   // ---- the (up to) 6 halo pieces this thread stages in every slice: LDS offset and position inside the halo ----------
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv_down3_kernel(const D3Params p) {
 
   struct Item { int n, y0, x0, tn; };
   auto decode = [&](int k) {
-    const int item = lb + k * nbx;
+    const int item = (p.lists == 0 && k == nfull) ? rstart + xidx : lb + k * nbx;
     Item it;
     it.tn = item % p.ntn;
     const int tm = item / p.ntn;
@@ -679,7 +686,7 @@ static int down3_launch(const void* src16, const void* wpack, const float* bias,
   p.gsrc = (const __bf16*)g16; p.bcoef = bcoef;
   p.clk = lg_clock_census();
   { static int lo = -1; if (lo < 0) lo = lg_env_flag("LG_D3_LDS_ORDER") ? 1 : 0; p.lds_order = lo; }   // (cached per call site)
-  { static int ol = -1; if (ol < 0) ol = lg_env_flag("LG_D3_OLD_LISTS") ? 1 : 0; p.old_lists = ol; }
+  { static int ol = -1; if (ol < 0) { const char* e = getenv("LG_D3_LISTS"); ol = (e && *e >= '0' && *e <= '2') ? *e - '0' : 0; } p.lists = ol; }
   { static int sm = -1; if (sm < 0) sm = lg_env_flag("LG_D3_SLICE_MAJOR") ? 1 : 0; p.slice_major = (sm && !pair && !nstats && !g16) ? 1 : 0; }   // layout experiment
   static int bpc = 0;   // resident blocks per CU
   if (!bpc) {
