@@ -32,6 +32,7 @@ struct WgAtParams {
   int B, Hm, Wm, Cb, Cs;
   int nuj, nunits;      // units = (Cb/32) x (Cs/64)
   int items_total, items_per;
+  int nsplit, interleave;   // interleave (round 5, LG_WGAT_INTERLEAVE): split s walks items s, s + nsplit, ... — the chip sweeps the maps front to back together
 };
 
 // SW == 8 is the 8x8-map configuration: an item is a PAIR of samples (2 x 64 small pixels = 8 k steps), each with its own
@@ -76,7 +77,9 @@ __global__ __launch_bounds__(512) void wgrad_at_kernel(const WgAtParams p) {
   const int bx = lg_xcd_remap(blockIdx.x, gridDim.x);
   const int unit = bx % p.nunits, split = bx / p.nunits;   // units of one split run together: they share the pixels
   const int i0 = (unit / p.nuj) * 32, j0 = (unit % p.nuj) * 64;
-  const int it0 = split * p.items_per, it1 = min(it0 + p.items_per, p.items_total);
+  const int it0 = p.interleave ? 0 : split * p.items_per;
+  const int it1 = p.interleave ? (p.items_total - split + p.nsplit - 1) / p.nsplit : min(it0 + p.items_per, p.items_total);   // local item indices it0 .. it1 - 1
+  auto item_of = [&](int j) { return p.interleave ? split + j * p.nsplit : j; };
   const int nxs = p.Wm / SW, nyb = p.Hm / R;
   const int Hb = 2 * p.Hm, Wb = 2 * p.Wm;
 
@@ -157,13 +160,13 @@ __global__ __launch_bounds__(512) void wgrad_at_kernel(const WgAtParams p) {
   }
 
   if (it0 < it1) {
-    load_item(it0);
+    load_item(item_of(it0));
     store_item(smem);
   }
   __syncthreads();
   for (int it = it0; it < it1; ++it) {
     const int cur = (it - it0) & 1;
-    if (it + 1 < it1 && !(LG_WGAT_DBG & 4)) load_item(it + 1);
+    if (it + 1 < it1 && !(LG_WGAT_DBG & 4)) load_item(item_of(it + 1));
     const char* sb = smem + cur * C::BUF;
     // k-step offsets of the two operands (compile-time once the loop is unrolled).  PAIR: k step ks = rows 2(ks&3),
     // 2(ks&3)+1 of sample ks >> 2; otherwise the 16 pixels of chunk xc of row yy.
@@ -303,6 +306,8 @@ extern "C" int lg_wgrad_at_try(const void* big16, const void* small16, void* wor
   p.nuj = cs / 64; p.nunits = (cb / 32) * (cs / 64);
   int ns;
   at_plan(B, Hm, Wm, cb, cs, sw, &ns, &p.items_total, &p.items_per);
+  p.nsplit = ns;
+  { static int il = -1; if (il < 0) il = lg_env_flag("LG_WGAT_INTERLEAVE") ? 1 : 0; p.interleave = il; }
   LG_CHECK_ARG(ws_bytes >= (size_t)ns * 25 * cb * cs * sizeof(float), "lg_wgrad_at: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   static bool attr = false;
