@@ -51,6 +51,7 @@ struct U4Params {
   int B, Hs, Ws, Cs, N, N32, KB;
   int tpi_x, tpi, ntn, nper, nparts;   // nper = items per class
   int gend[4];         // block ranges: class rank rk (taps 9, 6, 6, 4) owns blocks [gend[rk-1], gend[rk])
+  int xcdmajor;        // class-pair mode: XCD-major block ranks inside a type (LG_U4_XCD; see the kernel)
   int pairmode;        // 1 (default): blocks [0, gend[0]) run classes 3 then 0, blocks [gend[0], gend[1]) classes 1 then 2 (see the kernel)
   LgNormFuse nf;
 };
@@ -372,14 +373,20 @@ __global__ __launch_bounds__(256, 2) void conv_up4_kernel(const U4Params p) {
   // back — still ONE slice body per loop, so no register growth — and a pair is 13 or 12 tap units: 256 + 256 blocks take exactly
   // one item of each of their classes.  Measured: see DESIGN 10.
   if (p.pairmode) {
-    if (b < p.gend[0]) {
-      up4_run<3, STATS, FUSE, PAIR>(p, smem, b, p.gend[0]);
+    // xcdmajor (round 5, LG_U4_XCD): a block's rank inside its type is XCD-major (lg_xcd_remap) — consecutive items, i.e. the column tiles of
+    // one source tile and neighbouring tiles, then run on ONE XCD and share its L2 (with the plain rank they are dealt round-robin over
+    // the eight L2s).  Valid while the hardware deals blocks to XCDs by blockIdx & 7 and gend[0] is a multiple of 8 (checked on the host).
+    const int ga = p.gend[0], gb = p.gend[1] - p.gend[0];
+    if (b < ga) {
+      const int lb = p.xcdmajor ? lg_xcd_remap(b, ga) : b;
+      up4_run<3, STATS, FUSE, PAIR>(p, smem, lb, ga);
       __syncthreads();
-      up4_run<0, STATS, FUSE, PAIR>(p, smem, b, p.gend[0]);
+      up4_run<0, STATS, FUSE, PAIR>(p, smem, lb, ga);
     } else {
-      up4_run<1, STATS, FUSE, PAIR>(p, smem, b - p.gend[0], p.gend[1] - p.gend[0]);
+      const int lb = p.xcdmajor ? lg_xcd_remap(b - ga, gb) : b - ga;
+      up4_run<1, STATS, FUSE, PAIR>(p, smem, lb, gb);
       __syncthreads();
-      up4_run<2, STATS, FUSE, PAIR>(p, smem, b - p.gend[0], p.gend[1] - p.gend[0]);
+      up4_run<2, STATS, FUSE, PAIR>(p, smem, lb, gb);
     }
     return;
   }
@@ -453,6 +460,7 @@ extern "C" int lg_conv_up4_nf_try(const void* src16, const void* wpack_up, const
       if (best < 0 || cost < best) { best = cost; ga_best = ga; gb_best = gb; }
     }
     p.gend[0] = ga_best; p.gend[1] = ga_best + gb_best; p.gend[2] = p.gend[3] = p.gend[1];
+    { static int xm = -1; if (xm < 0) xm = lg_env_flag("LG_U4_XCD") ? 1 : 0; p.xcdmajor = (xm && ga_best % 8 == 0) ? 1 : 0; }
     grid = ga_best + gb_best;
   } else
   {
