@@ -380,8 +380,12 @@ def main():
         # they are collected on this same command and committed (scripts/collect_profiles.sh -> scripts/pmc_traffic.py)
         traffic, traffic_src = None, None
         import glob
-        tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")),
-                        key=lambda f: int(os.path.basename(f)[1:].split("_")[0]))
+        import re
+
+        def _round_key(f):   # r5_..., r5b_... (a second collection of a round): (5, ""), (5, "b") — never a parse error on a file name
+            m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(f))
+            return (int(m.group(1)), m.group(2)) if m else (-1, "")
+        tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")), key=_round_key)
         if a.workload == "c3" and dt_name == "bf16" and world == 1 and tfiles:
             tpath = tfiles[-1]   # the newest round's counter passes
             rec = json.load(open(tpath)).get(tag)
