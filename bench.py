@@ -115,6 +115,17 @@ def cpu_baseline(workload, full=False):
     return out
 
 
+def traffic_files():
+    """profiles/r<N>[suffix]_pmc_traffic.json, oldest first: r5_..., then r5b_... (a second collection of a round) — never a parse error on a name."""
+    import glob
+    import re
+
+    def key(f):
+        m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(f))
+        return (int(m.group(1)), m.group(2)) if m else (-1, "")
+    return sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")), key=key)
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` without a launcher: start N FRESH rank processes (torch.distributed.run, one per GPU)
     before this process has touched the GPU, relay their output (rank 0 prints the JSON line) and exit with the
@@ -380,12 +391,7 @@ def main():
         # they are collected on this same command and committed (scripts/collect_profiles.sh -> scripts/pmc_traffic.py)
         traffic, traffic_src = None, None
         import glob
-        import re
-
-        def _round_key(f):   # r5_..., r5b_... (a second collection of a round): (5, ""), (5, "b") — never a parse error on a file name
-            m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(f))
-            return (int(m.group(1)), m.group(2)) if m else (-1, "")
-        tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")), key=_round_key)
+        tfiles = traffic_files()
         if a.workload == "c3" and dt_name == "bf16" and world == 1 and tfiles:
             tpath = tfiles[-1]   # the newest round's counter passes
             rec = json.load(open(tpath)).get(tag)

@@ -139,3 +139,15 @@ def test_main_cli_modes(tmp_path):
     run("evaluate-sample")
     assert (rd / "evaluate" / "gen" / "8.jpg").is_file() and (rd / "evaluate" / "adj" / "real_1.jpg").is_file()
     assert "exported" in run("export-model") and (rd / "model" / "model.pt").is_file()
+
+
+def test_bench_finds_its_committed_traffic_file():
+    """bench.py reads the dominant kernel's HBM traffic from the newest committed counter collection; a file name it cannot parse must
+    not break the bench line (round 5: a second collection of a round, r5b_, did)."""
+    import json
+    import bench
+    files = bench.traffic_files()
+    assert files and all(os.path.basename(f).startswith("r") for f in files)
+    rounds = [int("".join(ch for ch in os.path.basename(f)[1:].split("_")[0] if ch.isdigit())) for f in files]
+    assert rounds == sorted(rounds)
+    assert isinstance(json.load(open(files[-1])), dict)
