@@ -53,18 +53,13 @@ constexpr int RING = 8;
 // NTT = tiles per workgroup step.  Waves = NTT * WN * 4 classes: 8 (one workgroup per CU) or, for N = 32 with ONE tile per step,
 // 4 (TWO independent workgroups per CU, 58 KB of LDS each: one's staging / row-store / barrier phases fall into the other's
 // MFMA phase — r3 stamps of the 8-wave form at N = 32: 49 % of a step is not MFMA time and nothing overlaps it).
-// HV (round 5, the N = 32 level with one tile per step): a wave owns TWO (class, pixel half) units instead of one class on all 128 pixels —
-// waves 0 / 1: class 3 on half 0 / 1, then class 0 on the other half; waves 2 / 3: class 1, then class 2 — 13 / 13 / 12 / 12 tap units of 2 row
-// tiles per step instead of 9 / 6 / 6 / 4 of 4: the step's barrier no longer waits for one 9-tap wave (the fixed roles need no rotation).
-// Price: every weight fragment feeds 2 MFMAs instead of 4 (two waves fetch each class's fragments).
-template <int CS, int N, int NTT = 2 / (N / 32), bool HVF = false> struct Cfg {
-  static constexpr bool HV = HVF;
+template <int CS, int N, int NTT = 2 / (N / 32)> struct Cfg {
   static constexpr int WN = N / 32;               // column waves per tile (2 | 1)
   static constexpr int NT = NTT;                  // tiles per workgroup step
   static constexpr int NWAVES = NT * WN * 4, THREADS = 64 * NWAVES;
   // 4-wave form: a wave's class ROTATES from step to step (order 3, 1, 0, 2): the waves of a workgroup sit on different SIMDs
   // and the classes have 9 / 6 / 6 / 4 taps — fixed roles would leave one SIMD with 2.25 x the matrix work of another
-  static constexpr bool ROT = NWAVES == 4 && !HVF;
+  static constexpr bool ROT = NWAVES == 4;
   static constexpr int PITCH = CS * 2 + 16;       // halo pixel pitch (bytes): consecutive pixels shift by one 16-B slot
   static constexpr int HB = NPX * PITCH;          // halo bytes per tile
   static constexpr int OPX = 4 * TH * TW;         // 512 output pixels per tile
@@ -105,11 +100,10 @@ constexpr int ntaps_of(int cls) { return nk(cls >> 1) * nk(cls & 1); }
 constexpr int tap_k(int p, int a) { return p ? 2 * a : 2 * a + 1; }
 constexpr int tap_d(int p, int a) { return (p + 1 - tap_k(p, a)) / 2; }
 
-template <int CS, int N, bool STATS, bool FUSE = false, int NTT = 2 / (N / 32), bool HVF = false>
-__global__ __launch_bounds__((Cfg<CS, N, NTT, HVF>::THREADS), 2) void conv_up3_kernel(const U3Params p) {
+template <int CS, int N, bool STATS, bool FUSE = false, int NTT = 2 / (N / 32)>
+__global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel(const U3Params p) {
   static_assert(!(STATS && FUSE), "forward moments and backward sums are never needed together");
-  static_assert(!HVF || (N == 32 && NTT == 1 && !FUSE), "the pixel-half form exists for the forward forms of the N = 32 level, one tile per step");
-  using C = Cfg<CS, N, NTT, HVF>;
+  using C = Cfg<CS, N, NTT>;
   constexpr int NTH = C::THREADS, NWV = C::NWAVES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f32x2* sstat = reinterpret_cast<f32x2*>(smem + C::SRED_OFF);
@@ -131,8 +125,7 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT, HVF>::THREADS), 2) void conv_up3_k
   // (scripts/probe/u3_rotoff_ab.sh, convT4 forward at B = 256): 145.3 / 143.1 us in phase, 141.4 (offset 1), 142.7 / 143.8 (offset 2) —
   // the matrix pipe's balance is not what bounds this layer; default 0.
   const int rsh = (C::ROT && (int)blockIdx.x >= (G + 1) / 2) ? p.rotoff : 0;
-  int cls = C::ROT ? rot_class(wid + rsh) : C::HV ? (wid < 2 ? 3 : 1) : cls_fixed;   // HV: the class of the wave's FIRST unit
-  const int hvhalf = wid & 1;   // HV: pixel half (tile rows 4 hvhalf .. + 3) of the first unit; the second unit takes the other half
+  int cls = C::ROT ? rot_class(wid + rsh) : cls_fixed;
   const int lb = lg_xcd_remap(blockIdx.x, G);
   const int nsteps_all = (p.nitems + C::NT - 1) / C::NT;       // steps (NT tiles each) over the whole problem
   const int nmine = (nsteps_all - lb + G - 1) / G;
@@ -203,21 +196,13 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT, HVF>::THREADS), 2) void conv_up3_k
     const int m = i * 32 + pix32(r);
     abase[i] = tsel * C::HB + ((m >> 4) * HWT + (m & 15)) * C::PITCH + h * 16;
   }
-  int abA[2], abB[2];   // HV: bases of the two row tiles of the first / second unit
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int mA = (2 * hvhalf + i) * 32 + pix32(r), mB = (2 * (hvhalf ^ 1) + i) * 32 + pix32(r);
-    abA[i] = ((mA >> 4) * HWT + (mA & 15)) * C::PITCH + h * 16;
-    abB[i] = ((mB >> 4) * HWT + (mB & 15)) * C::PITCH + h * 16;
-  }
-  (void)abA; (void)abB;
   const unsigned lane16 = lane * 16;
   const char* wwave = p.wp + (long long)wn * C::KB * 1024;      // this wave's column tile
   constexpr unsigned WTAP = (unsigned)(N / 32) * C::KB * 1024u;  // bytes from one tap's fragments to the next tap's
 
   u32x4 bf[RING];
   u32x4 hv[C::PPT];
-  f32x16 acc[C::HV ? 2 : 4];
+  f32x16 acc[4];
 
   // fragment f of class CLS: tap = f / KB, k-step = f % KB
   // (an opaque zero added per tile keeps the 72 fragment addresses out of loop-invariant VGPRs; the POINTER itself must
@@ -281,25 +266,23 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT, HVF>::THREADS), 2) void conv_up3_k
   };
 
   // one class of one tile: F = taps * KB fragments, ring position OFF at entry (F % RING != 0 only for CS = 64, class 3)
-  auto run_rows = [&](auto cls_c, auto off_c, auto next_c, auto sweep_c, const auto& abase, auto& acc) {
+  auto run_class = [&](auto cls_c, auto off_c, auto next_c) {
     constexpr int CLS = decltype(cls_c)::value, OFF = decltype(off_c)::value;
-    constexpr bool SWEEP = decltype(sweep_c)::value;   // this loop carries the deferred row sweep of the previous tile
-    constexpr int NI = (int)(sizeof(acc) / sizeof(acc[0]));   // row tiles of 32 pixels: 4 (a class on the whole tile) | 2 (HV: on a pixel half)
     constexpr int PY = CLS >> 1, PX = CLS & 1, NKX = nk(PX), F = ntaps_of(CLS) * C::KB;
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
     wzero = 0;
     asm volatile("" : "+s"(wzero));  // opaque to LICM (a scalar pair; the adds below are SALU)
-    bf16x8 a[2][NI];
+    bf16x8 a[2][4];
     auto a_off = [&](int f) {  // compile-time after unrolling
       const int t = f / C::KB, kb = f - t * C::KB;
       const int ta = t / NKX, tb = t - ta * NKX;
       return ((tap_d(PY, ta) + 1) * HWT + tap_d(PX, tb) + 1) * C::PITCH + kb * 32;
     };
 #pragma unroll
-    for (int i = 0; i < NI; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(smem + abase[i] + a_off(0));
+    for (int i = 0; i < 4; ++i) a[0][i] = *reinterpret_cast<const bf16x8*>(smem + abase[i] + a_off(0));
     __builtin_amdgcn_sched_barrier(0);
     // (a compile-time loop: with the deferred row sweep's f-dependent pieces inside, "#pragma unroll" left the 72-fragment loop
     //  rolled — ring slots through s_set_gpr_idx)
@@ -307,12 +290,12 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT, HVF>::THREADS), 2) void conv_up3_k
       constexpr int f = decltype(f_c)::value;
       if constexpr (f + 1 < F) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) a[(f + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(smem + abase[i] + a_off(f + 1 < F ? f + 1 : 0));
+        for (int i = 0; i < 4; ++i) a[(f + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(smem + abase[i] + a_off(f + 1 < F ? f + 1 : 0));
       }
       if constexpr (LG_U3_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
       const int sl = (f + OFF) % RING;
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
+      for (int i = 0; i < 4; ++i)
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[sl]), a[f & 1][i], acc[i], 0, 0, 0);
       if constexpr (LG_U3_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
       // the stream wraps: the same class every step — or (ROT) runs on into the first fragments of the wave's NEXT class
@@ -320,9 +303,9 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT, HVF>::THREADS), 2) void conv_up3_k
       else bf[sl] = *reinterpret_cast<const u32x4*>(frag_ptr(next_c, f + RING - F));
       // deferred row sweep of the previous tile: piece q is read from the staging area at fragment 1 + q STEP and stored one STEP later
       constexpr int STEP = F >= 2 * NPC + 2 ? 2 : 1;
-      static_assert(!(DEFER && SWEEP) || F >= NPC * STEP + 2, "class loop too short for the deferred row sweep");
-      constexpr bool RD = DEFER && SWEEP && f >= 1 && (f - 1) % STEP == 0 && (f - 1) / STEP < NPC;
-      constexpr bool ST = DEFER && SWEEP && f >= 1 + STEP && (f - 1 - STEP) % STEP == 0 && (f - 1 - STEP) / STEP < NPC;
+      static_assert(!DEFER || F >= NPC * STEP + 2, "class loop too short for the deferred row sweep");
+      constexpr bool RD = DEFER && f >= 1 && (f - 1) % STEP == 0 && (f - 1) / STEP < NPC;
+      constexpr bool ST = DEFER && f >= 1 + STEP && (f - 1 - STEP) % STEP == 0 && (f - 1 - STEP) / STEP < NPC;
       // The pieces sit between two sched_barrier(0) at the fragment boundary.  Handed to the group pipeline below as groups of their
       // own (VMEM write, DS read), the piece read could be picked by ANY earlier "DS read" group: the whole class loop came out scrambled
       // (ring waits collapsed to vmcnt(0..3), MFMAs of different fragments interleaved, 12 min of compile time).
@@ -334,7 +317,7 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT, HVF>::THREADS), 2) void conv_up3_k
         __builtin_amdgcn_sched_barrier(0);
       } else {  // one MFMA, one LDS read in its shadow, ..., the ring refill behind the last MFMA (see conv_down3.hip)
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
+        for (int i = 0; i < 4; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
@@ -342,9 +325,6 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT, HVF>::THREADS), 2) void conv_up3_k
       }
     });
   };
-  f32x16 accB[C::HV ? 2 : 1];   // HV: the second unit's accumulators (the first unit's are acc[0], acc[1])
-  (void)accB;
-  auto run_class = [&](auto cls_c, auto off_c, auto next_c) { run_rows(cls_c, off_c, next_c, std::true_type{}, abase, acc); };
 
 #ifdef LG_U3_STAMPS
   int nst = 0;
@@ -361,19 +341,7 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT, HVF>::THREADS), 2) void conv_up3_k
 
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>; using IH = std::integral_constant<int, (RING / 2) % RING>;
-    if constexpr (C::HV) {
-      // two (class, pixel half) units per wave and step; the ring runs on from the first unit into the second and from there into the next
-      // step's first (fragment counts 36 + 16 | 24 + 24: the ring position at the first unit's entry toggles 0 / RING / 2 for waves 0, 1)
-      using T = std::true_type; using Fz = std::false_type;
-      if (wid < 2) {
-        if (roff == 0) { run_rows(I3{}, I0{}, I0{}, T{}, abA, acc); run_rows(I0{}, IH{}, I3{}, Fz{}, abB, accB); }
-        else { run_rows(I3{}, IH{}, I0{}, T{}, abA, acc); run_rows(I0{}, I0{}, I3{}, Fz{}, abB, accB); }
-        roff = (roff + (ntaps_of(3) + ntaps_of(0)) * C::KB) % RING;
-      } else {
-        run_rows(I1{}, I0{}, I2{}, T{}, abA, acc);
-        run_rows(I2{}, I0{}, I1{}, Fz{}, abB, accB);
-      }
-    } else if constexpr (C::ROT) {
+    if constexpr (C::ROT) {
       // rotation 3 -> 1 -> 0 -> 2 -> 3 ...; the ring position at a class's entry is 0 or RING / 2 (only the 9-tap class of the
       // 64-channel form has a fragment count that is not a multiple of RING): both instantiations of every class
       if (cls == 3) { if (roff == 0) run_class(I3{}, I0{}, I1{}); else run_class(I3{}, IH{}, I1{}); }
@@ -399,19 +367,16 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT, HVF>::THREADS), 2) void conv_up3_k
     // ---- this wave's class into the output-tile staging area: acc[i][e] = channel (e&3) + 8*(e>>2) + 4*h of pixel m ----------
     {
       char* Cst = smem + C::C_OFF + tsel * C::CB;
+      const int py = cls >> 1, px = cls & 1;
       const float shift = STATS ? sbias[0] : 0.f;
       const f32x2 shift2 = {shift, shift};
       f32x2 s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
       f32x4 bq[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const f32x4*>(sbias + wn * 32 + 8 * g + 4 * h);
-      // one (class, first row tile) unit: the whole tile (4 row tiles), or — HV — a pixel half (2 row tiles from i0 on)
-      auto stage_unit = [&](int ucls, int i0, const auto& acc) __attribute__((always_inline)) {
-      constexpr int NIu = (int)(sizeof(acc) / sizeof(acc[0]));
-      const int py = ucls >> 1, px = ucls & 1;
 #pragma unroll
-      for (int i = 0; i < NIu; ++i) {
-        const int m = (i0 + i) * 32 + pix32(r);
+      for (int i = 0; i < 4; ++i) {
+        const int m = i * 32 + pix32(r);
         const int o = (2 * (m >> 4) + py) * (2 * TW) + 2 * (m & 15) + px;  // output pixel inside the 16 x 32 tile
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -431,11 +396,6 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT, HVF>::THREADS), 2) void conv_up3_k
           *reinterpret_cast<bf16x4*>(Cst + o * C::CROW + ((((wn * 4 + g) ^ (o >> 1)) & PM) << 4) + 8 * h) = w;
         }
       }
-      };
-      if constexpr (C::HV) {
-        stage_unit(wid < 2 ? 3 : 1, 2 * hvhalf, acc);
-        stage_unit(wid < 2 ? 0 : 2, 2 * (hvhalf ^ 1), accB);
-      } else stage_unit(cls, 0, acc);
       if constexpr (STATS) sstat[tid] = f32x2{s1v[0] + s1v[1], s2v[0] + s2v[1]};  // reduced by ONE wave per tile behind the barrier
     }
     U3_STAMP();  // staged
@@ -554,22 +514,22 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT, HVF>::THREADS), 2) void conv_up3_k
   }
 }
 
-template <int CS, int N, int NTT = 2 / (N / 32), bool HVF = false>
+template <int CS, int N, int NTT = 2 / (N / 32)>
 int launch_up3(U3Params p, bool stats, hipStream_t st, bool fuse = false) {
-  using C = Cfg<CS, N, NTT, HVF>;
+  using C = Cfg<CS, N, NTT>;
   static bool attr_set = false;
   const int nblk = (C::NWAVES == 8 ? 1 : 2) * lg_grid_cus();  // one 8-wave workgroup per CU, or two independent 4-wave ones
   if (!attr_set) {
     attr_set = true;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, true, false, NTT, HVF>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false, false, NTT, HVF>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false, true, NTT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, true, false, NTT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false, false, NTT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_up3_kernel<CS, N, false, true, NTT>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
   }
   const int nsteps = (p.nitems + C::NT - 1) / C::NT;
   const int grid = nsteps < nblk ? nsteps : nblk;
-  if (fuse) hipLaunchKernelGGL((conv_up3_kernel<CS, N, false, true, NTT, false>), dim3(grid), dim3(C::THREADS), C::LDS, st, p);
-  else if (stats) hipLaunchKernelGGL((conv_up3_kernel<CS, N, true, false, NTT, HVF>), dim3(grid), dim3(C::THREADS), C::LDS, st, p);
-  else hipLaunchKernelGGL((conv_up3_kernel<CS, N, false, false, NTT, HVF>), dim3(grid), dim3(C::THREADS), C::LDS, st, p);
+  if (fuse) hipLaunchKernelGGL((conv_up3_kernel<CS, N, false, true, NTT>), dim3(grid), dim3(C::THREADS), C::LDS, st, p);
+  else if (stats) hipLaunchKernelGGL((conv_up3_kernel<CS, N, true, false, NTT>), dim3(grid), dim3(C::THREADS), C::LDS, st, p);
+  else hipLaunchKernelGGL((conv_up3_kernel<CS, N, false, false, NTT>), dim3(grid), dim3(C::THREADS), C::LDS, st, p);
   return LG_OK;
 }
 
@@ -607,9 +567,8 @@ extern "C" int lg_conv_up3_nf_try(const void* src16, const void* wpack_up, const
 #endif
   // N = 32: two independent 4-wave workgroups per CU, one tile per step (LG_U3_T4_8W=1: the round-2 form, one 8-wave workgroup
   // with two tiles per step)
-  static int t4_8w = -1, no_hv = -1;
+  static int t4_8w = -1;
   if (t4_8w < 0) t4_8w = lg_env_flag("LG_U3_T4_8W") ? 1 : 0;
-  if (no_hv < 0) no_hv = lg_env_flag("LG_U3_NO_HALVES") ? 1 : 0;   // A/B: one class per wave on all 128 pixels, rotating (rounds 3-4)
   { static int ro = -1; if (ro < 0) { const char* e = getenv("LG_U3_ROTOFF"); ro = e ? (atoi(e) & 3) : 0; } p.rotoff = ro; }   // A/B (round 5, measured: 141 - 145 us for offsets 0 / 1 / 2 — no effect, default 0)
   // the norm-backward sums are produced by the one-tile-per-step forms only: with two tiles per step a thread's row sweep covers
   // both tiles, i.e. possibly two samples, and the per-thread sums would mix them (no layer of the step asks for that form)
@@ -623,10 +582,9 @@ extern "C" int lg_conv_up3_nf_try(const void* src16, const void* wpack_up, const
   hipStream_t st = (hipStream_t)stream;
   if (Cs == 128) launch_up3<128, 64>(p, stats, st, fuse);
   else if (t4_8w) launch_up3<64, 32>(p, stats, st, fuse);
-  else if (fuse || no_hv) launch_up3<64, 32, 1>(p, stats, st, fuse);
-  else launch_up3<64, 32, 1, true>(p, stats, st, false);
+  else launch_up3<64, 32, 1>(p, stats, st, fuse);
   LG_CHECK_LAUNCH("lg_conv_up3");
-  lg_note_kernel(Cs == 128 ? "conv_up3_kernel<128,64>" : t4_8w ? "conv_up3_kernel<64,32>" : (fuse || no_hv) ? "conv_up3_kernel<64,32,4w>" : "conv_up3_kernel<64,32,4w,halves>");
+  lg_note_kernel(Cs == 128 ? "conv_up3_kernel<128,64>" : t4_8w ? "conv_up3_kernel<64,32>" : "conv_up3_kernel<64,32,4w>");
   if (stats || fuse) *nparts_out = p.tpi;
   return LG_OK;
 }

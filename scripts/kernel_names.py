@@ -54,9 +54,8 @@ def short(name):
             return "conv_down3_kernel<PAIR>"
         norm = {"true": ",NORM", "1": ",NORM", "2": ",BWDNORM"}.get(t(4, "0"), "")
         return f"conv_down3_kernel<NW={t(3, '128')}{norm}>"
-    if base == "conv_up3_kernel":        # <CS, N, STATS, FUSE, NTT = tiles per step, HV = pixel-half units>; (64, 32) with one tile per step = the 4-wave form
-        four = t(1) == "32" and t(4, "2") == "1"
-        return f"conv_up3_kernel<{t(0)},{t(1)}" + (",4w,halves>" if (four and t(5, "false") == "true") else ",4w>" if four else ">")
+    if base == "conv_up3_kernel":        # <CS, N, STATS, FUSE, NTT = tiles per step>; (64, 32) with one tile per step = the 4-wave form
+        return f"conv_up3_kernel<{t(0)},{t(1)}" + (",4w>" if (t(1) == "32" and t(4, "2") == "1") else ">")
     if base == "conv_halo_kernel":       # <T, MODE, KCH, DBUF, SRC16, RES, ...>
         ty = "bf16" if t(0) == "__bf16" else "f32"
         mode = t(1)

@@ -26,8 +26,6 @@ CASES = [
     ("conv_up3_kernel<128, 64, false, true>", "conv_up3_kernel<128,64>"),
     ("void (anonymous namespace)::conv_up3_kernel<64, 32, true, false>((anonymous namespace)::U3Params)", "conv_up3_kernel<64,32>"),
     ("conv_up3_kernel<64, 32, true, false, 1>", "conv_up3_kernel<64,32,4w>"),
-    ("conv_up3_kernel<64, 32, true, false, 1, false>", "conv_up3_kernel<64,32,4w>"),
-    ("conv_up3_kernel<64, 32, true, false, 1, true>", "conv_up3_kernel<64,32,4w,halves>"),
     ("conv_up3_kernel<64, 32, true, false, 2>", "conv_up3_kernel<64,32>"),
     ("conv_up3_kernel<128, 64, false, true, 1>", "conv_up3_kernel<128,64>"),
     ("conv_up4_kernel<true, false>", "conv_up4_kernel"),
