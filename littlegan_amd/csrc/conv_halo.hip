@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include "lg_common.h"
 
+extern "C" int lg_device_cus(void);
+
 namespace {
 
 enum { MODE_DOWN = 0, MODE_UP = 1, MODE_S1T = 2 };
@@ -53,6 +55,9 @@ struct HaloParams {
   int cfg;                     // tile-shape switches (LG_CFG env, A/B)
   int* nparts_host;            // host-side: receives nparts of the launched tiling (moments epilogue on)
   int epi_rows;                // rows per pass of the LDS-transposed epilogue (0 = straight from the accumulators)
+  int ksplit;                  // 1, or 2: blockIdx.z takes one half of the channel chunks and ADDS its tile into the zeroed output (see launch)
+  int clsorder;                // UP: 1 = blockIdx.y -> class 3, 2, 0, 1 instead of 3, 2, 1, 0 (see the kernel)
+  int ntm, mfast;              // row tiles of the grid; mfast = 1: consecutive blocks of an XCD walk the ROW tiles of one column tile (see the kernel)
 };
 
 template <typename T> struct DT;
@@ -125,10 +130,16 @@ __global__ __launch_bounds__(256, (W3 ? LG_EXP_W3OCC : 2)) void conv_halo_kernel
   const int lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  int cls = (MODE == MODE_UP) ? (3 - (int)blockIdx.y) : 0;  // RES: set per pass of the class loop below
+  // UP: blockIdx.y -> parity class, heaviest first (9, 6, 6, 4 taps).  A grid of about one round (512 blocks: the exact-f32 layers at
+  // B = 64) is placed breadth first, so the blocks of y and y + 2 share a CU: with the order 3, 2, 1, 0 that is (9 + 6 | 6 + 4) taps per
+  // SIMD; clsorder puts the 4-tap class third — (9 + 4 | 6 + 6) (round 5).
+  int cls = (MODE == MODE_UP) ? (p.clsorder ? ((0x1023 >> (4 * (int)blockIdx.y)) & 3) : 3 - (int)blockIdx.y) : 0;  // RES: set per pass of the class loop below
   int py = cls >> 1, px = cls & 1;
   const int lb = lg_xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_n = lb % p.ntn, tile_m = lb / p.ntn;
+  // lb -> (row tile, column tile).  Column tile fastest (the first form): the blocks an XCD holds at one time share their SOURCE tiles and
+  // stream the WHOLE weight tensor between them — fine while that fits the XCD's 4 MB of L2.  mfast: row tile fastest — an XCD's blocks share
+  // one or two column slices of the weights and read disjoint source tiles (launch() sets it where the weights are the larger stream).
+  const int tile_n = p.mfast ? lb / p.ntm : lb % p.ntn, tile_m = p.mfast ? lb - tile_n * p.ntm : lb / p.ntn;
   const int n0 = tile_n * BN;
 
   // tile origin
@@ -193,7 +204,10 @@ __global__ __launch_bounds__(256, (W3 ? LG_EXP_W3OCC : 2)) void conv_halo_kernel
   if (MODE == MODE_UP) ntaps = (py ? 3 : 2) * (px ? 3 : 2);
   else ntaps = 25;
   if (p.dbg & 8) ntaps = 1;  // ablation: one tap per chunk -> fixed per-block cost (timing only)
-  const int nchunk = p.Cs / KC;
+  // ksplit == 2 (exact-f32 DOWN on the 8 x 8 maps): this block contracts chunks [c_lo, c_lo + nchunk) only
+  const int nchunk_all = p.Cs / KC;
+  const int c_lo = p.ksplit > 1 ? (int)blockIdx.z * nchunk_all / p.ksplit : 0;
+  const int nchunk = p.ksplit > 1 ? ((int)blockIdx.z + 1) * nchunk_all / p.ksplit - c_lo : nchunk_all;
 
   f32x16 acc[MT][NT];
 
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(256, (W3 ? LG_EXP_W3OCC : 2)) void conv_halo_kernel
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int q = 0; q < KCH; ++q) {
-        const char* g = p.wp + ((((long long)widx * N32 + nt0 + j) * KB + cc * KCH + q) * 64 + lane) * 16;
+        const char* g = p.wp + ((((long long)widx * N32 + nt0 + j) * KB + (c_lo + cc) * KCH + q) * 64 + lane) * 16;
         fb[j * KCH + q] = *reinterpret_cast<const u32x4*>(g);
       }
   };
@@ -358,7 +372,7 @@ __global__ __launch_bounds__(256, (W3 ? LG_EXP_W3OCC : 2)) void conv_halo_kernel
       if (cc + 1 < nchunk && !(p.dbg & 4)) {
         char* hnext = sH + (hsel ^ 1) * HBYTES;
         if (t > 0) halo_commit(hnext, (t - 1) * upt);
-        if (t + 1 < ntaps || ntaps == 1) halo_issue((cc + 1) * KC, t * upt);
+        if (t + 1 < ntaps || ntaps == 1) halo_issue((c_lo + cc + 1) * KC, t * upt);
         if (ntaps == 1) halo_commit(hnext, 0);
       }
     }
@@ -369,7 +383,7 @@ __global__ __launch_bounds__(256, (W3 ? LG_EXP_W3OCC : 2)) void conv_halo_kernel
       if constexpr (DBUF) {
         hsel ^= 1;
       } else {
-        stage_halo((cc + 1) * KC, sH);
+        stage_halo((c_lo + cc + 1) * KC, sH);
         __syncthreads();
       }
     }
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(256, (W3 ? LG_EXP_W3OCC : 2)) void conv_halo_kernel
     for (int u = 0; u < NSETS; ++u)
       if (u < nit) load_frags(fb[u], u);
     if constexpr (!RES) {
-      stage_halo(0, sH);
+      stage_halo(c_lo * KC, sH);
       __syncthreads();
     }
     for (int it = 0; it < nit; it += NSETS) {
@@ -416,7 +430,7 @@ __global__ __launch_bounds__(256, (W3 ? LG_EXP_W3OCC : 2)) void conv_halo_kernel
     constexpr bool TEPI = WAVES_N > 1 && !DBUF;  // RES: the halo stays live across the classes -> its own C region behind it
     bool tepi_done = false;
     if constexpr (TEPI) {
-      if (p.epi_rows > 0) {
+      if (p.epi_rows > 0 && p.ksplit <= 1) {
         tepi_done = true;
         constexpr int CP = BN + 4;  // row pitch (floats)
         float* C = reinterpret_cast<float*>(RES ? sH + (p.nrows * ROWB + 15) / 16 * 16 : sH);
@@ -453,6 +467,29 @@ __global__ __launch_bounds__(256, (W3 ? LG_EXP_W3OCC : 2)) void conv_halo_kernel
               } else {
                 *reinterpret_cast<f32x4*>(p.out + (long long)o * p.N + col) = v;
               }
+            }
+          }
+        }
+      }
+    }
+    if constexpr (sizeof(T) == 4 && !RES && !DBUF) {
+      // ksplit: the two halves of the contraction meet in the output, which the launcher zeroed: 0 + a + b and 0 + b + a are the same
+      // float (IEEE addition commutes; with THREE summands it would not), so the result does not depend on which block comes first.
+      // Bias rides with half 0; no activation, no fused moments (launch() declines both).
+      if (p.ksplit > 1) {
+        tepi_done = true;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int col = n0 + (wn * NT + j) * 32 + r;
+          const bool cok = col < p.N;
+          const float bv = (cok && p.bias && blockIdx.z == 0) ? p.bias[col] : 0.f;
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int row = (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+              const int o = so[row];
+              if (cok && o >= 0 && !(p.dbg & 16)) unsafeAtomicAdd(p.out + (long long)o * p.N + col, acc[i][j][e] + bv);
             }
           }
         }
@@ -615,9 +652,21 @@ int launch(HaloParams p, hipStream_t st) {
     if (res_epi) p.epi_rows = 32;
   }
   p.nparts = (MODE == MODE_UP ? 4 : 1) * p.tpi * p.ntn;
-  if (p.nparts_host) *p.nparts_host = p.nparts;
+  if (p.nparts_host) *p.nparts_host = p.ksplit > 1 ? 0 : p.nparts;
   const int ntm = p.NI == 1 ? p.B * p.tpi : lg_cdiv(p.B, p.NI);
-  dim3 grid(ntm * p.ntn, (MODE == MODE_UP && !RES) ? 4 : 1);
+  dim3 grid(ntm * p.ntn, (MODE == MODE_UP && !RES) ? 4 : 1, p.ksplit > 1 ? p.ksplit : 1);
+  p.ntm = ntm;
+  {
+    static int mf = -1;
+    if (mf < 0) { const char* e = getenv("LG_HALO_MFAST"); mf = e ? atoi(e) : 0; }   // 0 never, 1 where the weights exceed 2 MB, 2 always
+    const size_t wbytes = (size_t)(MODE == MODE_UP ? 25 : 25) * p.Cs * p.Npad * DT<T>::ESZ;
+    p.mfast = (p.mfast || mf == 2 || (mf == 1 && wbytes > (2u << 20))) && p.ntn > 1 ? 1 : 0;
+  }
+  {
+    static int co = -1;
+    if (co < 0) co = lg_env_flag("LG_NO_UP_CLSORDER") ? 0 : 1;
+    p.clsorder = co && MODE == MODE_UP && !RES && (int)grid.x * 4 <= 2 * lg_device_cus();   // one round only: over several rounds the lightest class should come last (convT3 forward at B = 64, 2048 blocks: 269 us in the order 9, 6, 6, 4 taps, 281 with the 4-tap class third)
+  }
   auto kern = conv_halo_kernel<T, MODE, KCH, DBUF, SRC16, RES, WAVES_M, WAVES_N, MT, NT, W3>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -625,6 +674,10 @@ int launch(HaloParams p, hipStream_t st) {
     attr_set = true;
   }
   if (p.dry) return LG_OK;
+  if (p.ksplit > 1 && hipMemsetAsync(p.out, 0, (size_t)p.B * p.Ho * p.Wo * p.N * sizeof(float), st) != hipSuccess) {
+    lg_set_error("lg_conv_halo: hipMemsetAsync of the split-contraction output failed");
+    return LG_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   lg_note_kernel(MODE == MODE_DOWN ? (sizeof(T) == 2 ? "conv_halo_kernel<bf16,DOWN>" : "conv_halo_kernel<f32,DOWN>")
                  : MODE == MODE_UP ? (RES ? "conv_halo_kernel<UP,resident>" : (sizeof(T) == 2 ? "conv_halo_kernel<bf16,UP,K-sliced>" : "conv_halo_kernel<f32,UP,K-sliced>"))
@@ -643,6 +696,35 @@ int dispatch_bn2(const HaloParams& p, hipStream_t st) {
     static int off = -1;
     if (off < 0) off = lg_env_flag("LG_NO_F32_NARROW") ? 1 : 0;
     narrow = !off && p.NI > 1 && p.Npad % 64 == 0;
+    // Round 5, the 8 x 8 maps at the C2 batches (scripts/probe/f32_ablate.sh, f32_tiling_ab.sh, f32_mfast_ab.sh).  These grids are
+    // ONE round of at most 512 blocks, every block in the same phase at the same time, so what counts is how evenly that round covers the
+    // 1024 SIMDs.  Measured per launch (us), conv4 forward (DOWN, 25 x 256 deep, N = 384) | convT1 forward (UP, 384 -> 256):
+    //     B = 64 : 64-column tiles 349 (192 blocks) , split 32-column 308-327, split 64-column 285, + row-tile-fastest 269 | 64-col 220, 128-col 274
+    //     B = 128: 64-column 482 (384 blocks), 128-column 507, split 32-col 482, split 64-col 520                          | 64-col 520, 128-col 380
+    // -> DOWN: up to 256 blocks of 64 columns are split in two over the channel chunks (blockIdx.z; both halves add into the zeroed output —
+    //    two summands commute, the result is deterministic; the moments come from the separate pass over the 6 MB map);
+    //    UP: 128-column tiles once they fill the 512 slots (4 classes x row tiles x N / 128 >= 512), 64-column tiles below that.
+    // The batch enters these two choices.  A tile's width does not change the conv result (an output element's contraction order is the
+    // same in every tiling), only the grouping of the fused moment records (their last bits); the SPLIT changes the result itself by the
+    // order of one addition per element.  Every OTHER choice here depends on the map only (tests compare a launch with its 32-image chunks
+    // bit for bit; at 32 against 64 images both sit on the same side of both thresholds, at 2B conv4 forward does not and the test bounds
+    // the difference instead: tests/test_launch_shapes_gpu.py, test_f32_8x8_level_tilings_that_depend_on_the_batch).
+    const int ntm2 = lg_cdiv(p.B, p.NI > 0 ? p.NI : 1);
+    if constexpr (MODE == MODE_DOWN) {
+      static int ks = -1;
+      if (ks < 0) ks = lg_env_flag("LG_NO_F32_KSPLIT") ? 0 : 1;
+      constexpr int KC = KCH * 32 / 4;
+      if (ks && narrow && p.act == 0 && !p.out16 && (p.Cs / KC) % 2 == 0 && (p.Cs / KC) >= 4 && ntm2 * (p.Npad / 64) <= 256) {
+        HaloParams q = p;
+        q.ksplit = 2; q.spart = nullptr; q.mfast = 1;
+        return launch<T, MODE, KCH, DBUF, SRC16, RES, 2, 2, 2, 1>(q, st);
+      }
+    }
+    if constexpr (MODE == MODE_UP) {
+      static int wide = -1;
+      if (wide < 0) wide = lg_env_flag("LG_NO_F32_UPWIDE") ? 0 : 1;
+      if (wide && narrow && p.Npad % 128 == 0 && 4 * ntm2 * (p.Npad / 128) >= 512) narrow = false;
+    }
   }
   if constexpr (!DBUF && !RES) if (!narrow) {  // tall wave tiles (128 rows x 64/32 cols): half the weight-fragment traffic per MFMA
     if (p.Npad % 256 == 0 && (p.cfg & 1)) return launch<T, MODE, KCH, DBUF, SRC16, RES, 1, 4, 4, 2>(p, st);

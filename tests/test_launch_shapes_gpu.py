@@ -709,6 +709,49 @@ def test_odd_batch_on_the_8x8_level_takes_another_kernel(ops, layer):
     assert np.abs(sa[:, :5] - sb[:, :5]).max() < 1e-4 * (np.abs(sa[:, :5]).max() + 1.0)
 
 
+@pytest.mark.parametrize("B", [64, 128])
+def test_f32_8x8_level_tilings_that_depend_on_the_batch(ops, B):
+    """Round 5 (conv_halo.hip, dispatch_bn2): on the exact-f32 path the 8 x 8 maps' grids are one round of blocks, and two choices now look at
+    the batch — conv4 forward splits its contraction in two halves that ADD into the zeroed output while the 64-column grid has at most
+    256 blocks (B = 64; not at 2B), convT1 forward takes 128-column tiles once they fill the 512 slots (2B; not at B).  Pinned: either
+    side of both thresholds is deterministic over three launches (two summands commute) and meets the fp64 oracle at the f32 bound of this
+    file; a launch equals its 32-image chunks bit for bit in z and in the statistics where both sit on the same side (B = 64).  At 2B they
+    do not: convT1's 128-column launch and its 64-column chunks give the same z and moment records grouped differently (statistics equal
+    to rounding); conv4's chunks are split and its full launch is not, and the two differ by the order of ONE addition per
+    output element over a 6400-term fp32 contraction (1.3e-6 rms measured — the size of either result's own distance to the fp64 oracle; bounded here)."""
+    gm, bt = torch.tensor([1.1], device="cuda"), torch.tensor([0.05], device="cuda")
+    for name in ("enc.conv4", "dec.conv1"):
+        _, kind, cb, cs, s = next(l for l in LAYERS if l[0] == name)
+        w = _rand((5, 5, cb, cs), 91, 0.05)
+        pack = ops.conv_pack(w, cb, cs, 0)
+        bias = _rand((cs if kind == "conv" else cb,), 92, 0.1)
+        x = _rand((B, 2 * s, 2 * s, cb) if kind == "conv" else (B, s, s, cs), 93)
+        def fwd(xs):
+            z, st = ops.conv2d_s2_fwd_stats(xs, pack, bias, cs, 0, gm, bt, alpha=ALPHA) if kind == "conv" else \
+                    ops.convT_s2_fwd_stats(xs, pack, bias, cb, 0, gm, bt, alpha=ALPHA)
+            st = ops.instnorm_stats(z, gm, bt, 0, ALPHA) if st is None else ops.stats_tensor(st)
+            return z.clone(), st.clone()
+
+        z, st = fwd(x)
+        for _ in range(2):
+            z2, st2 = fwd(x)
+            assert torch.equal(z2, z) and torch.equal(st2, st), (name, B, "launch-to-launch")
+        for lo in range(0, B, CHUNK):
+            zc, stc = fwd(x[lo:lo + CHUNK].contiguous())
+            if B > 64:   # the launch and its chunks sit on different sides: split | whole contraction, 128- | 64-column moment records
+                if kind == "conv":
+                    assert _rms(_f64(zc), _f64(z[lo:lo + CHUNK])) < 5e-6 and not torch.equal(zc, z[lo:lo + CHUNK]), (name, B, lo)
+                else:
+                    assert torch.equal(zc, z[lo:lo + CHUNK]), (name, B, lo)     # a tile's width does not change the conv result
+                assert np.abs(_f64(stc) - _f64(st[lo:lo + CHUNK])).max() < 1e-5 * (np.abs(_f64(st)).max() + 1.0), (name, B, lo, "stats")
+            else:
+                assert torch.equal(zc, z[lo:lo + CHUNK]), (name, B, lo)
+                assert torch.equal(stc, st[lo:lo + CHUNK]), (name, B, lo, "stats")
+        n = _samples(B)[:3]
+        ref = O.conv2d(_f64(x[n]), _f64(w), _f64(bias), 2) if kind == "conv" else O.conv2d_transpose(_f64(x[n]), _f64(w), _f64(bias), 2)
+        assert _rms(_f64(z[n]), ref) < 1e-5 and np.abs(_f64(z[n]) - ref).max() < 1e-4 * np.abs(ref).max(), (name, B)
+
+
 @pytest.mark.parametrize("B", [256, 512])
 @pytest.mark.parametrize("layer", [l for l in LAYERS if l[2] != 3], ids=[l[0] for l in LAYERS if l[2] != 3])
 def test_persistent_kernels_are_deterministic(ops, layer, B):
