@@ -299,8 +299,10 @@ __global__ __launch_bounds__((Cfg<CS, N, NTT>::THREADS), 2) void conv_up3_kernel
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[sl]), a[f & 1][i], acc[i], 0, 0, 0);
       if constexpr (LG_U3_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
       // the stream wraps: the same class every step — or (ROT) runs on into the first fragments of the wave's NEXT class
+#ifndef LG_U3_NO_WLOAD   // ablation (round 5, scripts/probe/u3_nowload.sh): the ring is primed once and never refilled — results wrong, timing only
       if constexpr (f + RING < F) bf[sl] = *reinterpret_cast<const u32x4*>(frag_ptr(cls_c, f + RING));
       else bf[sl] = *reinterpret_cast<const u32x4*>(frag_ptr(next_c, f + RING - F));
+#endif
       // deferred row sweep of the previous tile: piece q is read from the staging area at fragment 1 + q STEP and stored one STEP later
       constexpr int STEP = F >= 2 * NPC + 2 ? 2 : 1;
       static_assert(!DEFER || F >= NPC * STEP + 2, "class loop too short for the deferred row sweep");
