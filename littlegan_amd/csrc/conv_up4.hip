@@ -52,6 +52,7 @@ struct U4Params {
   int tpi_x, tpi, ntn, nper, nparts;   // nper = items per class
   int gend[4];         // block ranges: class rank rk (taps 9, 6, 6, 4) owns blocks [gend[rk-1], gend[rk])
   int xcdmajor;        // class-pair mode: XCD-major block ranks inside a type (LG_U4_XCD; see the kernel)
+  int mfast, ntm;      // mfast: item -> (row tile fastest, column tile); ntm = row tiles (LG_U4_MFAST, with xcdmajor: an XCD's blocks share ONE column tile's weights)
   int pairmode;        // 1 (default): blocks [0, gend[0]) run classes 3 then 0, blocks [gend[0], gend[1]) classes 1 then 2 (see the kernel)
   LgNormFuse nf;
 };
@@ -117,8 +118,8 @@ __device__ __forceinline__ void up4_run(const U4Params& p, char* smem, int lb, i
   auto decode = [&](int k) {
     const int rest = lb + k * G;
     Item it;
-    it.tn = rest % p.ntn;
-    const int tm = rest / p.ntn;
+    it.tn = p.mfast ? rest / p.ntm : rest % p.ntn;
+    const int tm = p.mfast ? rest - it.tn * p.ntm : rest / p.ntn;
     if constexpr (PAIR) { it.n = 2 * tm; it.y0 = 0; it.x0 = 0; return it; }
     it.n = tm / p.tpi;
     const int tt = tm - it.n * p.tpi;
@@ -461,6 +462,13 @@ extern "C" int lg_conv_up4_nf_try(const void* src16, const void* wpack_up, const
     }
     p.gend[0] = ga_best; p.gend[1] = ga_best + gb_best; p.gend[2] = p.gend[3] = p.gend[1];
     { static int xm = -1; if (xm < 0) xm = lg_env_flag("LG_U4_XCD") ? 1 : 0; p.xcdmajor = (xm && ga_best % 8 == 0) ? 1 : 0; }
+    {
+      static int mf = -1;
+      if (mf < 0) mf = lg_env_flag("LG_U4_MFAST") ? 1 : 0;
+      p.ntm = p.nper / p.ntn;
+      p.mfast = (mf && p.ntn > 1 && ga_best % 8 == 0 && gb_best % 8 == 0) ? 1 : 0;
+      if (p.mfast) p.xcdmajor = 1;
+    }
     grid = ga_best + gb_best;
   } else
   {

@@ -198,6 +198,18 @@ def _rccl_single_worker(outdir):
                 assert (x is None) == (y is None) and (x is None or torch.equal(x, y)), b
             for x, y in ((tr_p.store.flat, tr_s.store.flat), (tr_p.store.m, tr_s.store.m), (tr_p.store.v, tr_s.store.v), (tr_p.store.grad, tr_s.store.grad)):
                 assert torch.equal(x, y), b
+        # graph_step under data parallelism: the eager path, and it says so once
+        import warnings
+        inp = dev_inputs(_inputs(cfg, 1, 13))
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            rs = tr_s.graph_step(13, inp)
+            rp = tr_p.train_step_from_inputs(13, inp)
+            torch.cuda.synchronize()
+            for x, y in zip(rp, rs):
+                assert (x is None) == (y is None) and (x is None or torch.equal(x, y)), "graph_step under DP"
+            tr_s.graph_step(14, dev_inputs(_inputs(cfg, 1, 14)))
+        assert sum("eager path" in str(w.message) for w in caught) == 1, [str(w.message) for w in caught]
         loaded = [ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln or "libnccl" in ln]
         with open(os.path.join(outdir, "rccl_ok.txt"), "w") as f:
             f.write("\n".join(sorted(set(loaded))) or "none")
