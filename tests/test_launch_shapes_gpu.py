@@ -471,6 +471,29 @@ def test_whole_step_at_launch_batch(init_dim, B, chunk):
             assert r < 2e-3, (m, i, r)
 
 
+@pytest.mark.parametrize("dtype,B", [pytest.param("bf16", 256, id="C3-bf16-B256"), pytest.param("f32", 64, id="C2-f32-B64")])
+def test_whole_step_is_deterministic_at_launch_batch(dtype, B):
+    """Round 5 (taken from the kernels to the step): two trainers built from the same weights run the same three steps
+    (b = 10: a partition step, 11 and 12: full steps with the Adjuster branch and three Adam applies each) at the batch bench.py times, on
+    the same inputs.  EVERY bit of the outputs, losses, gradients, weights and Adam slots must agree: a launch-to-launch difference in any
+    of the step's ~190 launches (a packed-fp32 hazard; an atomic with three summands; a read of a buffer another launch still
+    writes) shows here at the sizes where round 4's build showed it.  Reference: eager_trainer.py:115-169."""
+    from test_step_gpu import build, dev_inputs, f32_round, perturbed
+    cfg = O.Cfg(init_dim=8, cond_dim=40, batch_size=B)
+    W = perturbed(cfg, 31)
+    tr1, tr2 = build(cfg, W, dtype), build(cfg, W, dtype)
+    for b in (10, 11, 12):
+        d_in = dev_inputs(f32_round(O.make_inputs(cfg, B, seed=40 + b)))
+        r1 = [None if t is None else t.clone() for t in tr1.train_step_from_inputs(b, d_in)]
+        r2 = tr2.train_step_from_inputs(b, d_in)
+        torch.cuda.synchronize()
+        for i, (x, y) in enumerate(zip(r1, r2)):
+            assert (x is None) == (y is None) and (x is None or torch.equal(x, y)), (dtype, b, "output", i)
+        for name in ("grad", "flat", "m", "v"):
+            assert torch.equal(getattr(tr1.store, name), getattr(tr2.store, name)), (dtype, b, name)
+    assert torch.isfinite(tr1.store.flat).all()
+
+
 def test_whole_f32_step_at_c2_batch():
     """The C2 configuration at its own batch (128x128, B = 64, exact-f32 MFMA, G + D step only, b = 5 is a partition step, b = 6 a full
     one): fake rows and both losses against the fp64 oracle on sampled rows / the whole batch is too slow on the CPU, so as above:
