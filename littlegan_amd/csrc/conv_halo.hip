@@ -107,14 +107,14 @@ template <typename T, int MODE, int KCH, bool DBUF, bool SRC16, bool RES, int WA
 __global__ __launch_bounds__(256, (W3 ? LG_EXP_W3OCC : 2)) void conv_halo_kernel(const HaloParams p) {
   static_assert(!W3 || halo_w3_ok<T, MODE, KCH, SRC16, RES, WAVES_M, MT, NT>(), "W3: DOWN, 32-channel chunks, bf16 mirror, 128x32 / 64x32 wave tiles");
   static_assert(!SRC16 || (sizeof(T) == 2 && !DBUF), "bf16 source only with bf16 MFMA, single-buffered halo");
-  static_assert(!RES || (SRC16 && MODE == MODE_UP), "resident halo: UP mode from the bf16 mirror");
+  static_assert(!RES || (MODE == MODE_UP && (SRC16 || sizeof(T) == 4)), "resident halo: UP mode, from the bf16 mirror or (round 5) exact f32");
   constexpr int ESZ = DT<T>::ESZ;
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
   static_assert(BM == 128, "halo tiles are 128 rows");
   constexpr int KC = KCH * 32 / ESZ;
   constexpr bool SWZ = W3 && MODE == MODE_DOWN;
   const int ROWB = RES ? p.Cs * ESZ + 16 : (SWZ ? KCH * 32 : KCH * 32 + 16);    // LDS bytes per halo row (RES: all channels)
-  const int LPR = RES ? p.Cs / 8 : (SRC16 ? KC / 8 : KC / 4);  // threads per halo row (16 B each: 4 fp32 or 8 bf16 channels)
+  const int LPR = RES ? (SRC16 ? p.Cs / 8 : p.Cs / 4) : (SRC16 ? KC / 8 : KC / 4);  // threads per halo row (16 B each: 4 fp32 or 8 bf16 channels)
   const int RPP = 256 / LPR;         // halo rows per pass
   constexpr int SS = (MODE == MODE_DOWN) ? 2 : 1;
   constexpr int LO = (MODE == MODE_S1T) ? -2 : -1;
@@ -680,7 +680,7 @@ int launch(HaloParams p, hipStream_t st) {
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   lg_note_kernel(MODE == MODE_DOWN ? (sizeof(T) == 2 ? "conv_halo_kernel<bf16,DOWN>" : "conv_halo_kernel<f32,DOWN>")
-                 : MODE == MODE_UP ? (RES ? "conv_halo_kernel<UP,resident>" : (sizeof(T) == 2 ? "conv_halo_kernel<bf16,UP,K-sliced>" : "conv_halo_kernel<f32,UP,K-sliced>"))
+                 : MODE == MODE_UP ? (RES ? (sizeof(T) == 2 ? "conv_halo_kernel<UP,resident>" : "conv_halo_kernel<f32,UP,resident>") : (sizeof(T) == 2 ? "conv_halo_kernel<bf16,UP,K-sliced>" : "conv_halo_kernel<f32,UP,K-sliced>"))
                  : "conv_halo_kernel<S1T>");
   return LG_OK;
 }
@@ -757,6 +757,17 @@ int dispatch_bn(const HaloParams& p, hipStream_t st) {
         }
       }
       return dispatch_bn2<T, MODE, KCH, false, true>(p, st);
+    }
+  }
+  if constexpr (sizeof(T) == 4 && MODE == MODE_UP && KCH == 4) {
+    // Round 5: the resident form for the exact-f32 N = 32 level (convT4 forward: 64 channels x 4 B = 49 KB of halo).  K-sliced, that layer is
+    // 8192 blocks of 32 x 32-pixel-by-column wave tiles, each a prologue (tables, halo, first fragments) for 64 .. 288 MFMAs per wave; resident,
+    // one block stages the tile once and runs the four classes' 800 MFMAs per wave behind it.  LG_NO_F32_RES=1 = before.
+    static int res32 = -1;
+    if (res32 < 0) res32 = lg_env_flag("LG_NO_F32_RES") ? 0 : 1;
+    if (res32 && p.res_budget > 0 && p.Npad == 32 && p.NI == 1 && p.Cs % 4 == 0 && 256 % (p.Cs / 4) == 0) {
+      rc = launch<T, MODE, KCH, false, false, true, 4, 1, 1, 1>(p, st);
+      if (rc != LG_ERR_UNSUPPORTED) return rc;
     }
   }
   if ((p.dbg & 64) && p.Cs / (KCH * 32 / DT<T>::ESZ) > 1) rc = dispatch_bn2<T, MODE, KCH, true, false>(p, st);  // double-buffered halo: measured slower, opt-in

@@ -64,7 +64,9 @@ def short(name):
         if mode == "0":
             return f"conv_halo_kernel<{ty},DOWN>"
         if mode == "1":
-            return "conv_halo_kernel<UP,resident>" if t(5) == "true" else f"conv_halo_kernel<{ty},UP,K-sliced>"
+            if t(5) == "true":
+                return "conv_halo_kernel<UP,resident>" if ty == "bf16" else "conv_halo_kernel<f32,UP,resident>"
+            return f"conv_halo_kernel<{ty},UP,K-sliced>"
         return "conv_halo_kernel<S1T>"
     if base == "conv_igemm_kernel":      # <T, MODE, ...>
         return "conv_igemm_kernel<%s>" % {"0": "DOWN", "1": "UP", "2": "S1T", "3": "PATCH"}.get(t(1), "?")

@@ -10,6 +10,7 @@ CASES = [
     ("conv_halo_kernel<bool _Accum, int, E, 4, false, true, false, 1, 4, 4, 1, true>", "conv_halo_kernel<bf16,UP,K-sliced>"),
     ("_ZN12_GLOBAL__N_116conv_halo_kernelIDF16bLi0ELi2ELb0ELb1ELb0ELi1ELi4ELi4ELi1ELb1EEEvNS_10HaloParamsE", "conv_halo_kernel<bf16,DOWN>"),
     ("_ZN12_GLOBAL__N_116conv_halo_kernelIDF16bLi1ELi4ELb0ELb1ELb1ELi1ELi4ELi4ELi1ELb0EEEvNS_10HaloParamsE", "conv_halo_kernel<UP,resident>"),
+    ("_ZN12_GLOBAL__N_116conv_halo_kernelIfLi1ELi4ELb0ELb0ELb1ELi4ELi1ELi1ELi1ELb0EEEvNS_10HaloParamsE", "conv_halo_kernel<f32,UP,resident>"),
     ("void (anonymous namespace)::conv_halo_kernel<float, 1, 2, false, false, false, 2, 2, 2, 1, false>(HaloParams)", "conv_halo_kernel<f32,UP,K-sliced>"),
     ("conv_down3_kernel<true, false, false, 128>", "conv_down3_kernel<NW=128>"),
     ("conv_down3_kernel<false, true, false, 64>", "conv_down3_kernel<NW=64>"),
