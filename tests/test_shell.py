@@ -151,3 +151,14 @@ def test_bench_finds_its_committed_traffic_file():
     rounds = [int("".join(ch for ch in os.path.basename(f)[1:].split("_")[0] if ch.isdigit())) for f in files]
     assert rounds == sorted(rounds)
     assert isinstance(json.load(open(files[-1])), dict)
+
+
+def test_bench_precision_note_quotes_the_other_dtype_of_the_same_workload():
+    """the bf16 headline and the exact-f32 step that meets the north star's tolerance are quoted side by side in
+    the bench line (`precision`); the figure comes from the newest committed collection whose own `dtype` field is the other one."""
+    import bench
+    n = bench.precision_note("c3", "bf16")
+    assert "1e-4" in n["this_line"] and n["other_dtype_same_workload"]["dtype"] == "f32"
+    assert n["other_dtype_same_workload"]["source"].startswith("profiles/") and n["other_dtype_same_workload"]["ms_per_step"] > 30
+    assert bench.precision_note("c3", "f32")["other_dtype_same_workload"]["dtype"] == "bf16"
+    assert bench.precision_note("c2", "f32")["other_dtype_same_workload"] is None   # c2's plain file IS the f32 run
