@@ -658,10 +658,22 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
   }
 }
 
+// Grid caps of the element-wise passes (blocks of 256 threads walking the map in trips).  LG_NORM_MAXBLK / LG_NORM_MAXBLK_DB: A/B of the cap
+// (round 5, scripts/probe/norm_maxblk.sh): fewer, longer-lived blocks against many short ones.
+inline long long ew_cap() {
+  static long long v = 0;
+  if (!v) { const char* e = getenv("LG_NORM_MAXBLK"); v = e && atoi(e) >= 64 ? atoi(e) : 8192; if (v > 8192) v = 8192; }
+  return v;
+}
+inline long long db_cap(long long hard) {
+  static long long v = 0;
+  if (!v) { const char* e = getenv("LG_NORM_MAXBLK_DB"); v = e && atoi(e) >= 64 ? atoi(e) : hard; if (v > hard) v = hard; }
+  return v;
+}
 inline int nchunks(long long L) { return (int)((L + CHUNK - 1) / CHUNK); }
 inline int ew_blocks(long long total4) {
   long long b = (total4 + 256 * EW_UNR - 1) / (256 * EW_UNR);
-  return (int)(b < 8192 ? (b > 0 ? b : 1) : 8192);
+  return (int)(b < ew_cap() ? (b > 0 ? b : 1) : ew_cap());
 }
 inline size_t part_bytes(int B, long long L) { return ((size_t)B * nchunks(L) * 3 * sizeof(double) + 255) / 256 * 256; }
 inline size_t bst_bytes(int B) { return ((size_t)B * 4 * sizeof(float) + 255) / 256 * 256; }
@@ -784,7 +796,7 @@ extern "C" int lg_instnorm_leaky_bwd_db(const float* x, const float* stats, cons
   }
   const int C4 = C / 4, unit = 256 % C4 == 0 ? 1 : 3;  // blocks per period of the thread -> channel map
   long long nb = (total4 + 255) / 256;
-  if (nb > DB_MAX_BLOCKS) nb = DB_MAX_BLOCKS;
+  if (nb > db_cap(DB_MAX_BLOCKS)) nb = db_cap(DB_MAX_BLOCKS) / 3 * 3;
   nb = (nb + unit - 1) / unit * unit;
   float* colpart = (float*)(ws + lg_instnorm_workspace_bytes(B, L));
   hipLaunchKernelGGL(bwd_apply_kernel<true>, dim3((int)nb), dim3(256), 0, st, x, g, g_is_bf16, stats, (const float*)bstats, dx,
@@ -806,7 +818,7 @@ extern "C" int lg_instnorm_leaky_apply_z16(const void* z16, const float* stats, 
                "lg_instnorm_leaky_apply_z16: bad shape B=%d L=%lld", B, L);
   const long long total8 = (long long)B * L / 8;
   long long nb = (total8 + 256 * EW8_UNR - 1) / (256 * EW8_UNR);
-  if (nb > 8192) nb = 8192;
+  if (nb > ew_cap()) nb = ew_cap();
   if (nb < 1) nb = 1;
   hipStream_t st = (hipStream_t)stream;
   const __bf16* x = (const __bf16*)z16;
@@ -833,7 +845,7 @@ extern "C" int lg_instnorm_leaky_apply_z16_p(const void* z16, const void* partia
                "lg_instnorm_leaky_apply_z16_p: bad shape B=%d L=%lld nparts=%d", B, L, nparts);
   const long long L8 = L / 8;
   long long bps = (L8 + 256 * EW8_UNR * 4 - 1) / (256 * EW8_UNR * 4);   // ~4 trips per block: the merge is paid once per 32 KB of z
-  if (bps * B > 8192) bps = 8192 / B;
+  if (bps * B > ew_cap()) bps = ew_cap() / B;
   if (bps < 1) bps = 1;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)bps, (unsigned)B);
@@ -911,7 +923,7 @@ extern "C" int lg_instnorm_leaky_bwd_z16_p(const void* z16, const float* stats, 
   const long long total8 = (long long)B * L / 8;
   if (!db) {
     long long nb = (total8 + 256 * EW8_UNR - 1) / (256 * EW8_UNR);
-    if (nb > 8192) nb = 8192;
+    if (nb > ew_cap()) nb = ew_cap();
     if (nb < 1) nb = 1;
     if (g_is_bf16)
       hipLaunchKernelGGL((bwd_apply16_kernel<false, true>), dim3((int)nb), dim3(256), 0, st, x, g, stats, (const float*)bstats, dx,
@@ -924,7 +936,7 @@ extern "C" int lg_instnorm_leaky_bwd_z16_p(const void* z16, const float* stats, 
   }
   const int C8 = C / 8, unit = 256 % C8 == 0 ? 1 : 3;
   long long nb = (total8 + 511) / 512;   // two units per thread per trip
-  if (nb > DB_MAX_BLOCKS) nb = DB_MAX_BLOCKS;
+  if (nb > db_cap(DB_MAX_BLOCKS)) nb = db_cap(DB_MAX_BLOCKS) / 3 * 3;
   if (nb < 1) nb = 1;
   nb = (nb + unit - 1) / unit * unit;
   float* colpart = (float*)(ws + lg_instnorm_workspace_bytes(B, L));   // [nb][C] floats, nb <= DB_MAX_BLOCKS (+2)
