@@ -670,6 +670,31 @@ inline long long db_cap(long long hard) {
   if (!v) { const char* e = getenv("LG_NORM_MAXBLK_DB"); v = e && atoi(e) >= 64 ? atoi(e) : hard; if (v > hard) v = hard; }
   return v;
 }
+// WHOLE ROUNDS (round 5).  These grids are larger than what the chip holds at once (blocks of 256 threads, 4 .. 8 per CU by their
+// VGPRs), so they run in rounds — and a last partial round costs a whole trip time for a fraction of the work: the bias-sum form of
+// the backward apply (71 VGPRs: 7 blocks per CU = 1792 resident) was launched as 2046 blocks = one round + 254 blocks, 14 % of a
+// round at the price of one (`scripts/probe/norm_maxblk.sh`: 1533 = six per CU beat both 2046 and 1023; C3 step -0.9 %).  A grid
+// beyond one round is cut to a whole number of rounds of the kernel's own residency (occupancy query, once per kernel).
+// LG_NO_NORM_ROUNDS=1 = the caps alone, as before.
+extern "C" int lg_device_cus(void);
+#define LG_RESIDENT_BLOCKS(kern)                                                                                       \
+  ([]() -> long long {                                                                                                 \
+    static long long r = 0;                                                                                            \
+    if (!r) {                                                                                                          \
+      int per_cu = 0;                                                                                                  \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 8; \
+      r = (long long)per_cu * lg_device_cus();                                                                         \
+    }                                                                                                                  \
+    return r;                                                                                                          \
+  }())
+inline long long fit_rounds(long long nb, long long resident, long long hard, int unit) {
+  static int off = -1;
+  if (off < 0) off = lg_env_flag("LG_NO_NORM_ROUNDS") ? 1 : 0;
+  if (nb > hard) nb = hard;
+  if (!off && nb > resident) nb = nb / resident * resident;
+  nb = nb / unit * unit;
+  return nb < unit ? unit : nb;
+}
 inline int nchunks(long long L) { return (int)((L + CHUNK - 1) / CHUNK); }
 inline int ew_blocks(long long total4) {
   long long b = (total4 + 256 * EW_UNR - 1) / (256 * EW_UNR);
@@ -730,7 +755,7 @@ extern "C" int lg_instnorm_leaky_apply(const float* x, const float* stats, const
   LG_CHECK_ARG(x && stats && (y || y16), "lg_instnorm_leaky_apply: null pointer");
   LG_CHECK_ARG(B > 0 && L > 0 && L % 4 == 0 && (long long)B * L / 4 < (1LL << 31), "lg_instnorm_leaky_apply: bad shape B=%d L=%lld", B, L);
   const long long total4 = (long long)B * L / 4;
-  hipLaunchKernelGGL(apply_kernel, dim3(ew_blocks(total4)), dim3(256), 0, (hipStream_t)stream, x, stats, skip, y,
+  hipLaunchKernelGGL(apply_kernel, dim3((int)fit_rounds(ew_blocks(total4), LG_RESIDENT_BLOCKS(apply_kernel), ew_cap(), 1)), dim3(256), 0, (hipStream_t)stream, x, stats, skip, y,
                      (__bf16*)y16, L / 4, total4, pre_leaky, post_leaky, alpha);
   LG_CHECK_LAUNCH("lg_instnorm_leaky_apply");
   return LG_OK;
@@ -789,15 +814,13 @@ extern "C" int lg_instnorm_leaky_bwd_db(const float* x, const float* stats, cons
   }
   const long long total4 = (long long)B * L / 4;
   if (!db) {
-    hipLaunchKernelGGL(bwd_apply_kernel<false>, dim3(ew_blocks(total4)), dim3(256), 0, st, x, g, g_is_bf16, stats,
+    hipLaunchKernelGGL(bwd_apply_kernel<false>, dim3((int)fit_rounds(ew_blocks(total4), LG_RESIDENT_BLOCKS(bwd_apply_kernel<false>), ew_cap(), 1)), dim3(256), 0, st, x, g, g_is_bf16, stats,
                        (const float*)bstats, dx, (__bf16*)dx16, L / 4, total4, pre_leaky, post_leaky, alpha, nullptr, 0);
     LG_CHECK_LAUNCH("lg_instnorm_leaky_bwd(apply)");
     return LG_OK;
   }
   const int C4 = C / 4, unit = 256 % C4 == 0 ? 1 : 3;  // blocks per period of the thread -> channel map
-  long long nb = (total4 + 255) / 256;
-  if (nb > db_cap(DB_MAX_BLOCKS)) nb = db_cap(DB_MAX_BLOCKS) / 3 * 3;
-  nb = (nb + unit - 1) / unit * unit;
+  long long nb = fit_rounds((total4 + 255) / 256, LG_RESIDENT_BLOCKS(bwd_apply_kernel<true>), db_cap(DB_MAX_BLOCKS), unit);
   float* colpart = (float*)(ws + lg_instnorm_workspace_bytes(B, L));
   hipLaunchKernelGGL(bwd_apply_kernel<true>, dim3((int)nb), dim3(256), 0, st, x, g, g_is_bf16, stats, (const float*)bstats, dx,
                      (__bf16*)dx16, L / 4, total4, pre_leaky, post_leaky, alpha, colpart, C4);
@@ -818,8 +841,7 @@ extern "C" int lg_instnorm_leaky_apply_z16(const void* z16, const float* stats, 
                "lg_instnorm_leaky_apply_z16: bad shape B=%d L=%lld", B, L);
   const long long total8 = (long long)B * L / 8;
   long long nb = (total8 + 256 * EW8_UNR - 1) / (256 * EW8_UNR);
-  if (nb > ew_cap()) nb = ew_cap();
-  if (nb < 1) nb = 1;
+  nb = fit_rounds(nb, !skip ? LG_RESIDENT_BLOCKS(apply16_kernel<0>) : !skip_is_bf16 ? LG_RESIDENT_BLOCKS(apply16_kernel<1>) : LG_RESIDENT_BLOCKS(apply16_kernel<2>), ew_cap(), 1);
   hipStream_t st = (hipStream_t)stream;
   const __bf16* x = (const __bf16*)z16;
   if (!skip)
@@ -923,8 +945,7 @@ extern "C" int lg_instnorm_leaky_bwd_z16_p(const void* z16, const float* stats, 
   const long long total8 = (long long)B * L / 8;
   if (!db) {
     long long nb = (total8 + 256 * EW8_UNR - 1) / (256 * EW8_UNR);
-    if (nb > ew_cap()) nb = ew_cap();
-    if (nb < 1) nb = 1;
+    nb = fit_rounds(nb, g_is_bf16 ? LG_RESIDENT_BLOCKS((bwd_apply16_kernel<false, true>)) : LG_RESIDENT_BLOCKS((bwd_apply16_kernel<false, false>)), ew_cap(), 1);
     if (g_is_bf16)
       hipLaunchKernelGGL((bwd_apply16_kernel<false, true>), dim3((int)nb), dim3(256), 0, st, x, g, stats, (const float*)bstats, dx,
                          (__bf16*)dx16, L / 8, total8, pre_leaky, post_leaky, alpha, (float*)nullptr, 0);
@@ -936,9 +957,7 @@ extern "C" int lg_instnorm_leaky_bwd_z16_p(const void* z16, const float* stats, 
   }
   const int C8 = C / 8, unit = 256 % C8 == 0 ? 1 : 3;
   long long nb = (total8 + 511) / 512;   // two units per thread per trip
-  if (nb > db_cap(DB_MAX_BLOCKS)) nb = db_cap(DB_MAX_BLOCKS) / 3 * 3;
-  if (nb < 1) nb = 1;
-  nb = (nb + unit - 1) / unit * unit;
+  nb = fit_rounds(nb, g_is_bf16 ? LG_RESIDENT_BLOCKS((bwd_apply16_kernel<true, true>)) : LG_RESIDENT_BLOCKS((bwd_apply16_kernel<true, false>)), db_cap(DB_MAX_BLOCKS), unit);
   float* colpart = (float*)(ws + lg_instnorm_workspace_bytes(B, L));   // [nb][C] floats, nb <= DB_MAX_BLOCKS (+2)
   if (g_is_bf16)
     hipLaunchKernelGGL((bwd_apply16_kernel<true, true>), dim3((int)nb), dim3(256), 0, st, x, g, stats, (const float*)bstats, dx,
