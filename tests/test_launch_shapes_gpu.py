@@ -775,6 +775,35 @@ def test_f32_8x8_level_tilings_that_depend_on_the_batch(ops, B):
         assert _rms(_f64(z[n]), ref) < 1e-5 and np.abs(_f64(z[n]) - ref).max() < 1e-4 * np.abs(ref).max(), (name, B)
 
 
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 84, 86, 126])
+def test_f32_tiling_rules_at_odd_batches_and_their_thresholds(ops, B):
+    """Round 5: the exact-f32 tiling rules of conv_halo.hip look at the batch — the split contraction of conv4 forward up to 256 blocks
+    (B <= 84 at 384 columns; 86 is the first unsplit batch), 128-column UP tiles from 512 blocks (B >= 128; 126 is the last narrow one) —
+    and the 8 x 8 maps are tiled in sample PAIRS, so an odd batch leaves half a tile empty.  Every one of these launches against the fp64
+    oracle on all its samples (the maps are small), plus the resident form of the N = 32 level at odd batches."""
+    gm, bt = torch.tensor([0.9], device="cuda"), torch.tensor([0.1], device="cuda")
+    cases = [("conv", 256, 384, 8), ("convT", 256, 384, 8)] + ([("convT", 32, 64, 64)] if B <= 5 else [])
+    for kind, cb, cs, s in cases:
+        w = _rand((5, 5, cb, cs), 95, 0.05)
+        pack = ops.conv_pack(w, cb, cs, 0)
+        bias = _rand((cs if kind == "conv" else cb,), 96, 0.1)
+        x = _rand((B, 2 * s, 2 * s, cb) if kind == "conv" else (B, s, s, cs), 97)
+        z, st = (ops.conv2d_s2_fwd_stats(x, pack, bias, cs, 0, gm, bt, alpha=ALPHA) if kind == "conv" else
+                 ops.convT_s2_fwd_stats(x, pack, bias, cb, 0, gm, bt, alpha=ALPHA))
+        kern = ops.last_kernel()
+        st = ops.instnorm_stats(z, gm, bt, 0, ALPHA) if st is None else ops.stats_tensor(st)
+        n = list(range(B)) if B <= 5 else [0, 1, B // 2, B - 2, B - 1]
+        ref = O.conv2d(_f64(x[n]), _f64(w), _f64(bias), 2) if kind == "conv" else O.conv2d_transpose(_f64(x[n]), _f64(w), _f64(bias), 2)
+        got = _f64(z[n])
+        assert _rms(got, ref) < 1e-5 and np.abs(got - ref).max() < 1e-4 * np.abs(ref).max(), (kind, cb, cs, B, kern)
+        mu, sg = ref.reshape(len(n), -1).mean(1), ref.reshape(len(n), -1).std(1)
+        s_ = _f64(st[n])
+        assert np.abs(s_[:, 0] + s_[:, 4] - mu).max() < 3e-6 * max(np.abs(mu).max(), sg.max()), (kind, B, kern)
+        assert np.abs(s_[:, 1] - sg).max() < 3e-6 * sg.max(), (kind, B, kern)
+        if kind == "convT" and cb == 32:
+            assert kern == "conv_halo_kernel<f32,UP,resident>", kern
+
+
 @pytest.mark.parametrize("B", [256, 512])
 @pytest.mark.parametrize("layer", [l for l in LAYERS if l[2] != 3], ids=[l[0] for l in LAYERS if l[2] != 3])
 def test_persistent_kernels_are_deterministic(ops, layer, B):
